@@ -1,0 +1,138 @@
+/*
+ * plz4hip.h -- C ABI of the MI355X (gfx950) LZ4 block engine that replaces plz4's cgo -> liblz4 engine.
+ *
+ * Drop-in boundary.  Today plz4 crosses from Go into C once per block through
+ * internal/pkg/clz4/clz4.go (CompressFast :31-45, DecompressSafe :47-60, CompressBound :27-29) underneath
+ * compress.Compressor / compress.Decompressor (internal/pkg/compress/compress.go:7-13, decompress.go:14-16),
+ * called from blk.CompressToBlk (internal/pkg/blk/blk.go:69-109), BlkT.Decompress (blk.go:50-61) and the
+ * raw block API (plz4_block.go:96-172); the per-block checksum is xxh32.ChecksumZero (blk.go:98-102,
+ * blk/frame.go:114-127).  One cgo call per 4 MiB block cannot feed a GPU, so this ABI is the same contract
+ * in BATCH form and sits where the reference's worker loops sit (async/writer.go:232-282 compressLoop,
+ * async/reader.go:192-221 _decompressLoop): N independent blocks in, N per-block results out.
+ * A one-block batch behaves exactly like the per-block call it replaces.
+ *
+ * Value semantics are liblz4's: encode result > 0 = bytes written, 0 = "cannot compress within dst"
+ * (clz4.ErrLz4Compress -> zerr.ErrCompress -> the caller stores the block raw, blk.go:78-92);
+ * decode result >= 0 = bytes, < 0 = liblz4's error code (clz4.ErrLz4Decompress -> zerr.ErrCorrupted).
+ * The function return value is separate and reports engine/runtime failures (PLZ4HIP_E_*); those must NOT be
+ * turned into stored blocks by the caller.
+ *
+ * Plain C, pointers and sizes only.  Host-pointer entry points never retain caller memory after return.
+ * Thread-safety: a ctx serialises its own calls with an internal mutex and calls hipSetDevice() on entry
+ * (goroutines migrate between OS threads); use one ctx per writer/reader for concurrency.
+ */
+#ifndef PLZ4HIP_H
+#define PLZ4HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLZ4HIP_ABI_VERSION 1
+
+enum {
+    PLZ4HIP_OK            =  0,
+    PLZ4HIP_E_ARG         = -1,   /* bad argument */
+    PLZ4HIP_E_DEVICE      = -2,   /* HIP runtime / kernel failure (see plz4hip_last_error) */
+    PLZ4HIP_E_NOMEM       = -3,   /* host or device allocation failed */
+    PLZ4HIP_E_UNSUPPORTED = -4    /* level / mode not built yet */
+};
+
+/* Per-block status of the record-level decode (plz4hip_decode_records, plz4hip_dev_decode_records). */
+enum {
+    PLZ4HIP_BLK_OK            = 0,
+    PLZ4HIP_BLK_HASH_MISMATCH = 1,   /* zerr.ErrBlockHash        (blk/frame.go:114-127) */
+    PLZ4HIP_BLK_SIZE_OVERFLOW = 2,   /* zerr.ErrBlockSizeOverflow (blk/frame.go:79-81)  */
+    PLZ4HIP_BLK_CORRUPT       = 3    /* zerr.ErrDecompress: liblz4 returned < 0 (compress/decompress.go:32-38) */
+};
+
+typedef struct plz4hip_ctx plz4hip_ctx;
+
+int         plz4hip_abi_version(void);
+int         plz4hip_device_count(void);                       /* <0: PLZ4HIP_E_DEVICE */
+int         plz4hip_ctx_create(int device, plz4hip_ctx** out);
+void        plz4hip_ctx_destroy(plz4hip_ctx* ctx);
+const char* plz4hip_last_error(const plz4hip_ctx* ctx);       /* text of the last PLZ4HIP_E_* on this ctx */
+
+/* == clz4.CompressBound (clz4.go:27-29) -> LZ4_compressBound (lz4.h:215).  Pure host arithmetic. */
+int plz4hip_compress_bound(int n);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * A. Batched Compressor / Decompressor over HOST buffers (what the cgo shim calls).
+ *    Replaces clz4.CompressFast (clz4.go:31-45) / clz4.DecompressSafe (clz4.go:47-60) x nBlocks.
+ *    level: 1 only in this round (level 1 == LZ4_compress_fast(accel 1), compress/indie.go:66-74).
+ *    result[i]: encode  > 0 bytes written into dst[i], 0 = liblz4 "does not fit dstCap[i]";
+ *               decode >= 0 bytes written, < 0 liblz4 error code.
+ * ------------------------------------------------------------------------------------------------------- */
+int plz4hip_compress_batch(plz4hip_ctx* ctx, int nBlocks,
+                           const void* const* src, const int32_t* srcLen,
+                           void* const* dst, const int32_t* dstCap,
+                           int level, int32_t* result);
+
+int plz4hip_decompress_batch(plz4hip_ctx* ctx, int nBlocks,
+                             const void* const* src, const int32_t* srcLen,
+                             void* const* dst, const int32_t* dstCap,
+                             int32_t* result);
+
+/* == xxh32.ChecksumZero (xxh32zero.go:238-280) x n. */
+int plz4hip_xxh32_batch(plz4hip_ctx* ctx, int n, const void* const* buf, const int32_t* len, uint32_t* out);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * B. Frame records over HOST buffers: blk.CompressToBlk (blk.go:69-109) / FrameReader._read + BlkT.Decompress
+ *    (blk/frame.go:54-127, blk.go:50-61) fused on the device.
+ *    encode: rec[i] (>= bsz+8 bytes) receives [LE32 size | 0x80000000 if stored][payload][LE32 xxh32(payload)?];
+ *            encoder capacity is bsz (NOT the bound); stored raw iff the encoder returns 0.  recLen[i] = bytes.
+ *    decode: rec[i]/recLen[i] is one such record (size word included); dst[i] has bsz+8 bytes like the
+ *            reference's pooled block (blk/pool.go:23-26); status[i] = PLZ4HIP_BLK_*, result[i] = plaintext bytes
+ *            (or liblz4's negative code when status is PLZ4HIP_BLK_CORRUPT).
+ * ------------------------------------------------------------------------------------------------------- */
+int plz4hip_encode_records(plz4hip_ctx* ctx, int nBlocks,
+                           const void* const* src, const int32_t* srcLen,
+                           int bsz, int level, int blockChecksum,
+                           void* const* rec, int32_t* recLen);
+
+int plz4hip_decode_records(plz4hip_ctx* ctx, int nBlocks,
+                           const void* const* rec, const int32_t* recLen,
+                           int bsz, int blockChecksum,
+                           void* const* dst, int32_t* result, int32_t* status);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * C. Device-resident pipeline (bench.py, GPU-to-GPU producers).  Every pointer below is a DEVICE pointer
+ *    on ctx's device; work is enqueued on `stream` (a hipStream_t, NULL = the ctx's own stream) and the call
+ *    returns without synchronising.  Layout:
+ *      src     plaintext, block i = src[i*bsz, min((i+1)*bsz, srcBytes))          nBlocks = ceil(srcBytes/bsz)
+ *      stage   nBlocks records at stride plz4hip_dev_stage_stride(bsz)             (scratch)
+ *      recLen  int32[nBlocks]   record i length (4 + payload + 4 if checksums)
+ *      recOff  int64[nBlocks+1] exclusive prefix sum of recLen (recOff[nBlocks] = body bytes)
+ *      body    the records, compacted back to back: exactly the frame's block section
+ *    plz4hip_dev_encode_records = encode kernel -> scan -> compaction.  body may be NULL to skip compaction.
+ *    plz4hip_dev_decode_records reads records at body+recOff[i] and writes block i at dst + i*dstStride
+ *    (capacity dstCap, bsz+8 in the reference); result/status as in B.
+ * ------------------------------------------------------------------------------------------------------- */
+int64_t plz4hip_dev_stage_stride(int bsz);
+
+int plz4hip_dev_encode_records(plz4hip_ctx* ctx, const void* src, int64_t srcBytes, int bsz, int level,
+                               int blockChecksum, void* stage, int32_t* recLen, int64_t* recOff,
+                               void* body, int64_t bodyCap, void* stream);
+
+int plz4hip_dev_decode_records(plz4hip_ctx* ctx, const void* body, const int64_t* recOff, int nBlocks,
+                               int bsz, int blockChecksum, void* dst, int64_t dstStride, int dstCap,
+                               int32_t* result, int32_t* status, void* stream);
+
+/* Raw LZ4 blocks on the device (no record framing): block i = src + i*srcStride (srcLen[i] bytes) ->
+ * dst + i*dstStride (capacity dstCap[i]); result[i] as in A.  srcLen/dstCap/result are device arrays. */
+int plz4hip_dev_compress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
+                         void* dst, int64_t dstStride, const int32_t* dstCap, int level, int32_t* result, void* stream);
+int plz4hip_dev_decompress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
+                           void* dst, int64_t dstStride, const int32_t* dstCap, int32_t* result, void* stream);
+
+/* Number of waves the encode / decode kernels keep resident on ctx's device (for sizing batches). */
+int plz4hip_dev_resident_waves(plz4hip_ctx* ctx, int decode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLZ4HIP_H */

@@ -1,0 +1,199 @@
+"""ctypes binding of the C ABI (include/plz4hip.h) implemented by plz4_amd/libplz4hip.so.
+
+There is NO fallback: if the HIP library is missing or cannot be loaded this module raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libplz4hip.so")
+
+ABI_VERSION = 1
+SYMBOLS = [
+    "plz4hip_abi_version", "plz4hip_device_count", "plz4hip_ctx_create", "plz4hip_ctx_destroy",
+    "plz4hip_last_error", "plz4hip_compress_bound", "plz4hip_compress_batch", "plz4hip_decompress_batch",
+    "plz4hip_xxh32_batch", "plz4hip_encode_records", "plz4hip_decode_records", "plz4hip_dev_stage_stride",
+    "plz4hip_dev_encode_records", "plz4hip_dev_decode_records", "plz4hip_dev_compress", "plz4hip_dev_decompress",
+    "plz4hip_dev_resident_waves",
+]
+
+E_NAMES = {0: "OK", -1: "E_ARG", -2: "E_DEVICE", -3: "E_NOMEM", -4: "E_UNSUPPORTED"}
+BLK_OK, BLK_HASH_MISMATCH, BLK_SIZE_OVERFLOW, BLK_CORRUPT = 0, 1, 2, 3
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("plz4hip: %s (%s)" % (E_NAMES.get(code, code), text))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("plz4_amd: %s is missing -- build it with `python -m plz4_amd.build` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (SONAME libamdhip64.so.7).  If torch
+    # is importable, load it FIRST so that our NEEDED libamdhip64.so.7 binds to the copy torch uses; loaded the
+    # other way round the process ends up with two runtimes and torch sees no GPU.
+    if os.environ.get("PLZ4_AMD_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    L = C.CDLL(LIB_PATH)
+    vp, i32p, i64p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    pp = C.POINTER(C.c_void_p)
+    L.plz4hip_abi_version.restype = C.c_int
+    L.plz4hip_device_count.restype = C.c_int
+    L.plz4hip_ctx_create.restype = C.c_int
+    L.plz4hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.plz4hip_ctx_destroy.argtypes = [vp]
+    L.plz4hip_last_error.restype = C.c_char_p
+    L.plz4hip_last_error.argtypes = [vp]
+    L.plz4hip_compress_bound.restype = C.c_int
+    L.plz4hip_compress_bound.argtypes = [C.c_int]
+    L.plz4hip_compress_batch.restype = C.c_int
+    L.plz4hip_compress_batch.argtypes = [vp, C.c_int, pp, i32p, pp, i32p, C.c_int, i32p]
+    L.plz4hip_decompress_batch.restype = C.c_int
+    L.plz4hip_decompress_batch.argtypes = [vp, C.c_int, pp, i32p, pp, i32p, i32p]
+    L.plz4hip_xxh32_batch.restype = C.c_int
+    L.plz4hip_xxh32_batch.argtypes = [vp, C.c_int, pp, i32p, C.POINTER(C.c_uint32)]
+    L.plz4hip_encode_records.restype = C.c_int
+    L.plz4hip_encode_records.argtypes = [vp, C.c_int, pp, i32p, C.c_int, C.c_int, C.c_int, pp, i32p]
+    L.plz4hip_decode_records.restype = C.c_int
+    L.plz4hip_decode_records.argtypes = [vp, C.c_int, pp, i32p, C.c_int, C.c_int, pp, i32p, i32p]
+    L.plz4hip_dev_stage_stride.restype = C.c_int64
+    L.plz4hip_dev_stage_stride.argtypes = [C.c_int]
+    L.plz4hip_dev_encode_records.restype = C.c_int
+    L.plz4hip_dev_encode_records.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int64, vp]
+    L.plz4hip_dev_decode_records.restype = C.c_int
+    L.plz4hip_dev_decode_records.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp, vp, vp]
+    L.plz4hip_dev_compress.restype = C.c_int
+    L.plz4hip_dev_compress.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int, vp, vp]
+    L.plz4hip_dev_decompress.restype = C.c_int
+    L.plz4hip_dev_decompress.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp, vp, vp]
+    L.plz4hip_dev_resident_waves.restype = C.c_int
+    L.plz4hip_dev_resident_waves.argtypes = [vp, C.c_int]
+    if L.plz4hip_abi_version() != ABI_VERSION:
+        raise ImportError("plz4_amd: libplz4hip.so ABI %d != binding %d" % (L.plz4hip_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def _ptr_array(bufs):
+    arr = (C.c_void_p * len(bufs))()
+    for i, b in enumerate(bufs):
+        arr[i] = b.ctypes.data if (b is not None and b.size) else None
+    return arr
+
+
+def _i32(vals):
+    return np.ascontiguousarray(np.asarray(vals, dtype=np.int32))
+
+
+def _i32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Engine:
+    """One plz4hip_ctx.  Mirrors the reference's per-worker Compressor/Decompressor instantiation
+    (internal/pkg/async/writer.go:237, compress/compress.go:50-57) in batch form."""
+
+    def __init__(self, device: int = 0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.plz4hip_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, "plz4hip_ctx_create(device=%d) failed -- is an MI355X visible?" % device)
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.plz4hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(rc, (self.L.plz4hip_last_error(self.h) or b"").decode())
+
+    @staticmethod
+    def compress_bound(n: int) -> int:
+        return int(load().plz4hip_compress_bound(n))
+
+    def resident_waves(self, decode: bool) -> int:
+        return int(self.L.plz4hip_dev_resident_waves(self.h, int(decode)))
+
+    # ---- A. batched Compressor / Decompressor over host buffers
+    def compress_batch(self, srcs, caps, level: int = 1):
+        n = len(srcs)
+        lens = _i32([s.size for s in srcs]); capa = _i32(caps)
+        dsts = [np.empty(max(int(c), 1), dtype=np.uint8) for c in caps]
+        res = np.zeros(n, dtype=np.int32)
+        self._chk(self.L.plz4hip_compress_batch(self.h, n, _ptr_array(srcs), _i32p(lens), _ptr_array(dsts), _i32p(capa),
+                                                level, _i32p(res)))
+        return res, [d[:max(int(r), 0)] for d, r in zip(dsts, res)]
+
+    def decompress_batch(self, srcs, caps):
+        n = len(srcs)
+        lens = _i32([s.size for s in srcs]); capa = _i32(caps)
+        dsts = [np.zeros(max(int(c), 1), dtype=np.uint8) for c in caps]
+        res = np.zeros(n, dtype=np.int32)
+        self._chk(self.L.plz4hip_decompress_batch(self.h, n, _ptr_array(srcs), _i32p(lens), _ptr_array(dsts), _i32p(capa),
+                                                  _i32p(res)))
+        return res, [d[:max(int(r), 0)] for d, r in zip(dsts, res)]
+
+    def xxh32_batch(self, bufs):
+        n = len(bufs)
+        lens = _i32([b.size for b in bufs])
+        out = np.zeros(n, dtype=np.uint32)
+        self._chk(self.L.plz4hip_xxh32_batch(self.h, n, _ptr_array(bufs), _i32p(lens), out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    # ---- B. frame records over host buffers
+    def encode_records(self, srcs, bsz: int, block_checksum: bool, level: int = 1):
+        n = len(srcs)
+        lens = _i32([s.size for s in srcs])
+        recs = [np.empty(bsz + 8, dtype=np.uint8) for _ in range(n)]
+        rl = np.zeros(n, dtype=np.int32)
+        self._chk(self.L.plz4hip_encode_records(self.h, n, _ptr_array(srcs), _i32p(lens), bsz, level, int(block_checksum),
+                                                _ptr_array(recs), _i32p(rl)))
+        return [r[:int(k)] for r, k in zip(recs, rl)]
+
+    def decode_records(self, recs, bsz: int, block_checksum: bool):
+        n = len(recs)
+        lens = _i32([r.size for r in recs])
+        dsts = [np.zeros(bsz + 8, dtype=np.uint8) for _ in range(n)]
+        res = np.zeros(n, dtype=np.int32); st = np.zeros(n, dtype=np.int32)
+        self._chk(self.L.plz4hip_decode_records(self.h, n, _ptr_array(recs), _i32p(lens), bsz, int(block_checksum),
+                                                _ptr_array(dsts), _i32p(res), _i32p(st)))
+        return res, st, [d[:max(int(r), 0)] for d, r in zip(dsts, res)]
+
+    # ---- C. device-resident pipeline (raw device pointers; torch tensors supply .data_ptr())
+    def dev_encode_records(self, src_ptr, src_bytes, bsz, block_checksum, stage_ptr, reclen_ptr, recoff_ptr,
+                           body_ptr, body_cap, stream=0, level: int = 1):
+        self._chk(self.L.plz4hip_dev_encode_records(self.h, src_ptr, src_bytes, bsz, level, int(block_checksum), stage_ptr,
+                                                    reclen_ptr, recoff_ptr, body_ptr, body_cap, stream))
+
+    def dev_decode_records(self, body_ptr, recoff_ptr, nblocks, bsz, block_checksum, dst_ptr, dst_stride, dst_cap,
+                           result_ptr, status_ptr, stream=0):
+        self._chk(self.L.plz4hip_dev_decode_records(self.h, body_ptr, recoff_ptr, nblocks, bsz, int(block_checksum), dst_ptr,
+                                                    dst_stride, dst_cap, result_ptr, status_ptr, stream))
+
+    def stage_stride(self, bsz: int) -> int:
+        return int(self.L.plz4hip_dev_stage_stride(bsz))

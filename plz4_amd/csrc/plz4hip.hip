@@ -1,0 +1,510 @@
+// plz4hip.hip -- gfx950 kernels + the C ABI declared in include/plz4hip.h.
+//
+// Launch shape: ONE 64-lane wavefront per LZ4 block, one wavefront per workgroup, persistent waves pulling
+// block indices from a device-side counter (every wave exits when the counter passes nBlocks).  The encoder
+// owns 16 KiB of LDS (liblz4's hash table, lz4.h:695-697) so 10 encoder waves fit a CU's 160 KiB; the decoder
+// uses no LDS and is bounded by the 32-waves/CU limit.  Independent blocks never communicate.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/plz4hip.h"
+#include "lz4_device.inl"
+
+namespace {
+
+using namespace plz4;
+
+// ------------------------------------------------------------------------------------------------ kernels
+struct CodecArgs {
+    const uint8_t* src;  int64_t srcStride;  const int32_t* srcLen;  int64_t srcBytes;  int bsz;
+    uint8_t*       dst;  int64_t dstStride;  const int32_t* dstCap;  int dstCapAll;
+    const int64_t* recOff;
+    int32_t*       result;
+    int32_t*       status;
+    uint32_t*      queue;
+    int            nBlocks;
+    int            blockChecksum;
+};
+
+__device__ __forceinline__ int next_block(uint32_t* q)
+{
+    uint32_t v = 0;
+    if ((threadIdx.x & 63u) == 0) v = atomicAdd(q, 1u);
+    return (int)plz4_readfirstlane(v);
+}
+
+__device__ __forceinline__ int block_len(const CodecArgs& a, int i)
+{
+    if (a.srcLen) return a.srcLen[i];
+    const int64_t rem = a.srcBytes - (int64_t)i * a.bsz;
+    return (int)(rem < a.bsz ? rem : a.bsz);
+}
+
+// LZ4 blocks only: dst[i] <- LZ4_compress_fast(src[i]), result[i] = bytes or 0.
+__global__ __launch_bounds__(64) void k_encode_raw(CodecArgs a)
+{
+    __shared__ uint32_t lds[kHashBytes / 4];
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int n   = block_len(a, i);
+        const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
+        const int r   = wave_encode_block(a.src + (int64_t)i * a.srcStride, n, a.dst + (int64_t)i * a.dstStride, cap, lds);
+        if ((threadIdx.x & 63u) == 0) a.result[i] = r;
+    }
+}
+
+// blk.CompressToBlk on the device: [LE32 size|stored][payload][LE32 xxh32?] at dst + i*dstStride.
+__global__ __launch_bounds__(64) void k_encode_rec(CodecArgs a)
+{
+    __shared__ uint32_t lds[kHashBytes / 4];
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int      n   = block_len(a, i);
+        const uint8_t* s   = a.src + (int64_t)i * a.srcStride;
+        uint8_t*       rec = a.dst + (int64_t)i * a.dstStride;
+        int      c    = wave_encode_block(s, n, rec + 4, a.bsz, lds);       // capacity == bsz (blk/blk.go:73)
+        uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
+        if (c == 0) {                                                        // ErrCompress -> stored raw (blk.go:78-92)
+            wave_copy(rec + 4, s, n);
+            c = n;
+            word = 0x80000000u | ((uint32_t)n & 0x7FFFFFFFu);
+        }
+        int len = c + 4;
+        if (a.blockChecksum) {                                               // over the payload as stored (blk.go:98-102)
+            WAVE_FENCE();
+            const uint32_t x = wave_xxh32(rec + 4, c);
+            if ((threadIdx.x & 63u) == 0) st32u(rec + 4 + c, x);
+            len += 4;
+        }
+        if ((threadIdx.x & 63u) == 0) { st32u(rec, word); a.result[i] = len; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_decode_raw(CodecArgs a)
+{
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int n   = a.srcLen[i];
+        const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
+        const int r   = wave_decode_block(a.src + (int64_t)i * a.srcStride, n, a.dst + (int64_t)i * a.dstStride, cap);
+        if ((threadIdx.x & 63u) == 0) a.result[i] = r;
+    }
+}
+
+// FrameReader._read's per-block checks + BlkT.Decompress on the device (blk/frame.go:54-127, blk.go:50-61).
+// Record i starts at src + recOff[i] when recOff is given, else at src + i*srcStride with srcLen[i] bytes.
+__global__ __launch_bounds__(64) void k_decode_rec(CodecArgs a)
+{
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const uint8_t* rec    = a.recOff ? a.src + a.recOff[i] : a.src + (int64_t)i * a.srcStride;
+        const int64_t  recLen = a.recOff ? a.recOff[i + 1] - a.recOff[i] : (int64_t)a.srcLen[i];
+        uint8_t*       out    = a.dst + (int64_t)i * a.dstStride;
+        const uint32_t word   = plz4_readfirstlane(ld32u(rec));
+        const int      sz     = (int)(word & 0x7FFFFFFFu);
+        int st = PLZ4HIP_BLK_OK, r = 0;
+        if (sz > a.bsz || (int64_t)sz + 4 + (a.blockChecksum ? 4 : 0) > recLen) {
+            st = PLZ4HIP_BLK_SIZE_OVERFLOW;
+        } else {
+            if (a.blockChecksum) {
+                const uint32_t want = plz4_readfirstlane(ld32u(rec + 4 + sz));
+                if (wave_xxh32(rec + 4, sz) != want) st = PLZ4HIP_BLK_HASH_MISMATCH;
+            }
+            if (st == PLZ4HIP_BLK_OK) {
+                if (word & 0x80000000u) {                                    // stored block: straight copy
+                    const int cap = a.dstCapAll;
+                    if (sz > cap) { st = PLZ4HIP_BLK_SIZE_OVERFLOW; }
+                    else { wave_copy(out, rec + 4, sz); r = sz; }
+                } else {
+                    r = wave_decode_block(rec + 4, sz, out, a.dstCapAll);
+                    if (r < 0) st = PLZ4HIP_BLK_CORRUPT;
+                }
+            }
+        }
+        if ((threadIdx.x & 63u) == 0) { a.result[i] = r; a.status[i] = st; }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_xxh32(const uint8_t* base, int64_t stride, const int32_t* len, uint32_t* out,
+                                              int n, uint32_t* queue)
+{
+    for (int i = next_block(queue); i < n; i = next_block(queue)) {
+        const uint32_t x = wave_xxh32(base + (int64_t)i * stride, len[i]);
+        if ((threadIdx.x & 63u) == 0) out[i] = x;
+    }
+}
+
+// Exclusive prefix sum int32 -> int64, one workgroup.
+__global__ __launch_bounds__(1024) void k_scan(const int32_t* __restrict__ len, int64_t* __restrict__ off, int n)
+{
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(t * per, n), hi = min(lo + per, n);
+    int64_t s = 0;
+    for (int i = lo; i < hi; ++i) s += len[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int64_t v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int64_t run = part[t] - s;
+    for (int i = lo; i < hi; ++i) { off[i] = run; run += len[i]; }
+    if (t == 1023) off[n] = part[1023];
+}
+
+// Records from the staging area (fixed stride) to their final, back-to-back place in the frame body.
+// grid = (nBlocks, slices); 256 threads copy 16 bytes each per step (unaligned on both sides is fine on gfx950).
+__global__ __launch_bounds__(256) void k_compact(const uint8_t* __restrict__ stage, int64_t stride,
+                                                 const int32_t* __restrict__ len, const int64_t* __restrict__ off,
+                                                 uint8_t* __restrict__ body)
+{
+    const int      i = blockIdx.x;
+    const int      n = len[i];
+    const uint8_t* s = stage + (int64_t)i * stride;
+    uint8_t*       d = body + off[i];
+    const int full = n & ~15;
+    for (int p = (blockIdx.y * 256 + threadIdx.x) * 16; p < full; p += gridDim.y * 256 * 16)
+        *(v16u_t*)(d + p) = *(const v16u_t*)(s + p);
+    if (blockIdx.y == 0 && threadIdx.x < (n - full)) d[full + threadIdx.x] = s[full + threadIdx.x];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ context
+struct plz4hip_ctx {
+    int          device = 0;
+    hipStream_t  stream = nullptr;
+    std::mutex   mu;
+    std::string  err;
+    uint32_t*    d_queues = nullptr;   // ring of work-queue counters
+    int          qslot = 0;
+    int          cus = 0;
+    int          encWaves = 0, decWaves = 0;
+    // host-API staging (grown on demand)
+    uint8_t*     h_pin = nullptr;  size_t h_cap = 0;
+    uint8_t*     d_buf = nullptr;  size_t d_cap = 0;
+};
+
+namespace {
+
+constexpr int kQueueSlots = 256;
+
+int fail(plz4hip_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (c) {
+        char buf[512];
+        if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        else snprintf(buf, sizeof buf, "%s", what);
+        c->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                         \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((ctx), PLZ4HIP_E_DEVICE, #call, e_); } while (0)
+
+uint32_t* next_queue(plz4hip_ctx* c, hipStream_t s, hipError_t* e)
+{
+    uint32_t* q = c->d_queues + c->qslot;
+    c->qslot = (c->qslot + 1) % kQueueSlots;
+    *e = hipMemsetAsync(q, 0, sizeof(uint32_t), s);
+    return q;
+}
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int ensure_staging(plz4hip_ctx* c, size_t hostBytes, size_t devBytes)
+{
+    if (hostBytes > c->h_cap) {
+        if (c->h_pin) hipHostFree(c->h_pin);
+        c->h_pin = nullptr; c->h_cap = 0;
+        const size_t want = round_up(hostBytes + (hostBytes >> 2), 1 << 20);
+        if (hipHostMalloc((void**)&c->h_pin, want, hipHostMallocDefault) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "hipHostMalloc");
+        c->h_cap = want;
+    }
+    if (devBytes > c->d_cap) {
+        if (c->d_buf) hipFree(c->d_buf);
+        c->d_buf = nullptr; c->d_cap = 0;
+        const size_t want = round_up(devBytes + (devBytes >> 2), 1 << 20);
+        if (hipMalloc((void**)&c->d_buf, want) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "hipMalloc");
+        c->d_cap = want;
+    }
+    return PLZ4HIP_OK;
+}
+
+int grid_for(int nBlocks, int resident) { return nBlocks < resident ? nBlocks : resident; }
+
+}  // namespace
+
+extern "C" {
+
+int plz4hip_abi_version(void) { return PLZ4HIP_ABI_VERSION; }
+
+int plz4hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return PLZ4HIP_E_DEVICE;
+    return n;
+}
+
+int plz4hip_compress_bound(int n) { return ((unsigned)n > 0x7E000000u) ? 0 : n + n / 255 + 16; }
+
+int64_t plz4hip_dev_stage_stride(int bsz) { return (int64_t)round_up((size_t)bsz + 8, 16); }
+
+int plz4hip_ctx_create(int device, plz4hip_ctx** out)
+{
+    if (!out) return PLZ4HIP_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return PLZ4HIP_E_DEVICE;
+    plz4hip_ctx* c = new (std::nothrow) plz4hip_ctx();
+    if (!c) return PLZ4HIP_E_NOMEM;
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_queues, kQueueSlots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device);
+    int encPer = 0, decPer = 0;
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&encPer, k_encode_rec, 64, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&decPer, k_decode_rec, 64, 0);
+    if (e != hipSuccess) {
+        fprintf(stderr, "plz4hip_ctx_create: %s\n", hipGetErrorString(e));
+        if (c->d_queues) hipFree(c->d_queues);
+        if (c->stream) hipStreamDestroy(c->stream);
+        delete c;
+        return PLZ4HIP_E_DEVICE;
+    }
+    if (encPer < 1) encPer = 1;
+    if (decPer < 1) decPer = 1;
+    c->encWaves = c->cus * encPer;
+    c->decWaves = c->cus * decPer;
+    *out = c;
+    return PLZ4HIP_OK;
+}
+
+void plz4hip_ctx_destroy(plz4hip_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+    if (c->d_queues) hipFree(c->d_queues);
+    if (c->h_pin) hipHostFree(c->h_pin);
+    if (c->d_buf) hipFree(c->d_buf);
+    delete c;
+}
+
+const char* plz4hip_last_error(const plz4hip_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int plz4hip_dev_resident_waves(plz4hip_ctx* c, int decode) { return c ? (decode ? c->decWaves : c->encWaves) : PLZ4HIP_E_ARG; }
+
+// ---------------------------------------------------------------------------------------- device-resident API
+int plz4hip_dev_compress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
+                         void* dst, int64_t dstStride, const int32_t* dstCap, int level, int32_t* result, void* stream)
+{
+    if (!c || nBlocks < 0 || !srcLen || !dstCap || !result) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_compress: bad argument");
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    if (nBlocks == 0) return PLZ4HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
+    CodecArgs a{};
+    a.src = (const uint8_t*)src; a.srcStride = srcStride; a.srcLen = srcLen;
+    a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCap = dstCap;
+    a.result = result; a.queue = q; a.nBlocks = nBlocks;
+    hipLaunchKernelGGL(k_encode_raw, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
+    HIPCHK(c, hipGetLastError());
+    return PLZ4HIP_OK;
+}
+
+int plz4hip_dev_decompress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
+                           void* dst, int64_t dstStride, const int32_t* dstCap, int32_t* result, void* stream)
+{
+    if (!c || nBlocks < 0 || !srcLen || !dstCap || !result) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_decompress: bad argument");
+    if (nBlocks == 0) return PLZ4HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
+    CodecArgs a{};
+    a.src = (const uint8_t*)src; a.srcStride = srcStride; a.srcLen = srcLen;
+    a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCap = dstCap;
+    a.result = result; a.queue = q; a.nBlocks = nBlocks;
+    hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
+    HIPCHK(c, hipGetLastError());
+    return PLZ4HIP_OK;
+}
+
+int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes, int bsz, int level,
+                               int blockChecksum, void* stage, int32_t* recLen, int64_t* recOff,
+                               void* body, int64_t bodyCap, void* stream)
+{
+    if (!c || srcBytes < 0 || bsz <= 0 || !stage || !recLen) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_encode_records: bad argument");
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    const int64_t nb64 = (srcBytes + bsz - 1) / bsz;
+    if (nb64 > 0x7FFFFFFF) return fail(c, PLZ4HIP_E_ARG, "too many blocks");
+    const int nBlocks = (int)nb64;
+    if (nBlocks == 0) return PLZ4HIP_OK;
+    if (body && (!recOff || bodyCap < srcBytes + (int64_t)nBlocks * 8)) return fail(c, PLZ4HIP_E_ARG, "body buffer too small (need srcBytes + 8*nBlocks)");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
+    const int64_t stride = plz4hip_dev_stage_stride(bsz);
+    CodecArgs a{};
+    a.src = (const uint8_t*)src; a.srcStride = bsz; a.srcBytes = srcBytes; a.bsz = bsz;
+    a.dst = (uint8_t*)stage; a.dstStride = stride;
+    a.result = recLen; a.queue = q; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
+    hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
+    HIPCHK(c, hipGetLastError());
+    if (recOff) {
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, recLen, recOff, nBlocks);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (body) {
+        const int slices = (bsz + 8 + 256 * 16 * 8 - 1) / (256 * 16 * 8);     // ~8 steps per thread on a full block
+        hipLaunchKernelGGL(k_compact, dim3(nBlocks, slices < 1 ? 1 : slices), dim3(256), 0, s,
+                           (const uint8_t*)stage, stride, recLen, recOff, (uint8_t*)body);
+        HIPCHK(c, hipGetLastError());
+    }
+    return PLZ4HIP_OK;
+}
+
+int plz4hip_dev_decode_records(plz4hip_ctx* c, const void* body, const int64_t* recOff, int nBlocks,
+                               int bsz, int blockChecksum, void* dst, int64_t dstStride, int dstCap,
+                               int32_t* result, int32_t* status, void* stream)
+{
+    if (!c || nBlocks < 0 || !body || !recOff || !dst || !result || !status || bsz <= 0) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_decode_records: bad argument");
+    if (nBlocks == 0) return PLZ4HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
+    CodecArgs a{};
+    a.src = (const uint8_t*)body; a.recOff = recOff; a.bsz = bsz;
+    a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCapAll = dstCap;
+    a.result = result; a.status = status; a.queue = q; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
+    hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
+    HIPCHK(c, hipGetLastError());
+    return PLZ4HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------- host-buffer API
+// Staging layout on both sides: [int32 lenA[n]] [int32 lenB[n]] [int32 res[n]] [int32 st[n]] [in blocks @inStride] [out blocks @outStride]
+namespace {
+struct Staging { size_t offA, offB, offRes, offSt, offIn, offOut, total; int64_t inStride, outStride; };
+
+Staging plan(int n, int maxIn, int maxOut)
+{
+    Staging s{};
+    const size_t arr = round_up((size_t)n * 4, 256);
+    s.offA = 0; s.offB = arr; s.offRes = 2 * arr; s.offSt = 3 * arr; s.offIn = 4 * arr;
+    s.inStride = (int64_t)round_up((size_t)maxIn + 16, 16);
+    s.outStride = (int64_t)round_up((size_t)maxOut + 16, 16);
+    s.offOut = s.offIn + (size_t)n * s.inStride;
+    s.total = s.offOut + (size_t)n * s.outStride;
+    return s;
+}
+}  // namespace
+
+static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3 dec rec,4 xxh*/, int nBlocks,
+                      const void* const* src, const int32_t* srcLen, void* const* dst, const int32_t* dstCap,
+                      int bsz, int blockChecksum, int32_t* result, int32_t* status)
+{
+    if (nBlocks == 0) return PLZ4HIP_OK;
+    int maxIn = 0, maxOut = 0;
+    for (int i = 0; i < nBlocks; ++i) {
+        if (srcLen[i] < 0 || (srcLen[i] > 0 && !src[i])) return fail(c, PLZ4HIP_E_ARG, "bad source block");
+        if (srcLen[i] > maxIn) maxIn = srcLen[i];
+        const int oc = (mode == 0 || mode == 1) ? dstCap[i] : (mode == 4 ? 4 : bsz + 8);
+        if (oc < 0) return fail(c, PLZ4HIP_E_ARG, "negative capacity");
+        if (oc > maxOut) maxOut = oc;
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const Staging st = plan(nBlocks, maxIn, maxOut);
+    if (int rc = ensure_staging(c, st.total, st.total)) return rc;
+    hipStream_t s = c->stream;
+    int32_t* hA = (int32_t*)(c->h_pin + st.offA);
+    int32_t* hB = (int32_t*)(c->h_pin + st.offB);
+    for (int i = 0; i < nBlocks; ++i) {
+        hA[i] = srcLen[i];
+        hB[i] = (mode == 0 || mode == 1) ? dstCap[i] : 0;
+        if (srcLen[i]) memcpy(c->h_pin + st.offIn + (size_t)i * st.inStride, src[i], (size_t)srcLen[i]);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_buf, c->h_pin, st.offIn + (size_t)nBlocks * st.inStride, hipMemcpyHostToDevice, s));
+    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
+    CodecArgs a{};
+    a.src = c->d_buf + st.offIn; a.srcStride = st.inStride; a.srcLen = (const int32_t*)(c->d_buf + st.offA);
+    a.dst = c->d_buf + st.offOut; a.dstStride = st.outStride; a.dstCap = (const int32_t*)(c->d_buf + st.offB);
+    a.result = (int32_t*)(c->d_buf + st.offRes); a.status = (int32_t*)(c->d_buf + st.offSt);
+    a.queue = q; a.nBlocks = nBlocks; a.bsz = bsz; a.blockChecksum = blockChecksum; a.dstCapAll = bsz + 8;
+    switch (mode) {
+    case 0: hipLaunchKernelGGL(k_encode_raw, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a); break;
+    case 2: a.dstCap = nullptr; hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
+    case 3: a.dstCap = nullptr; hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(k_xxh32, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s,
+                               (const uint8_t*)a.src, a.srcStride, a.srcLen, (uint32_t*)a.result, nBlocks, q); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    // results first, then only as much payload as the largest result needs per block would require a second pass;
+    // copy the output area back in one transfer.
+    HIPCHK(c, hipMemcpyAsync(c->h_pin + st.offRes, c->d_buf + st.offRes, 2 * (st.offSt - st.offRes), hipMemcpyDeviceToHost, s));
+    if (mode != 4)
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + st.offOut, c->d_buf + st.offOut, (size_t)nBlocks * st.outStride, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    const int32_t* hRes = (const int32_t*)(c->h_pin + st.offRes);
+    const int32_t* hSt  = (const int32_t*)(c->h_pin + st.offSt);
+    for (int i = 0; i < nBlocks; ++i) {
+        result[i] = hRes[i];
+        if (status) status[i] = hSt[i];
+        if (mode != 4 && hRes[i] > 0 && dst[i]) memcpy(dst[i], c->h_pin + st.offOut + (size_t)i * st.outStride, (size_t)hRes[i]);
+    }
+    return PLZ4HIP_OK;
+}
+
+int plz4hip_compress_batch(plz4hip_ctx* c, int nBlocks, const void* const* src, const int32_t* srcLen,
+                           void* const* dst, const int32_t* dstCap, int level, int32_t* result)
+{
+    if (!c || nBlocks < 0 || (nBlocks && (!src || !srcLen || !dst || !dstCap || !result))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_compress_batch: bad argument");
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    return host_codec(c, 0, nBlocks, src, srcLen, dst, dstCap, 0, 0, result, nullptr);
+}
+
+int plz4hip_decompress_batch(plz4hip_ctx* c, int nBlocks, const void* const* src, const int32_t* srcLen,
+                             void* const* dst, const int32_t* dstCap, int32_t* result)
+{
+    if (!c || nBlocks < 0 || (nBlocks && (!src || !srcLen || !dst || !dstCap || !result))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_decompress_batch: bad argument");
+    return host_codec(c, 1, nBlocks, src, srcLen, dst, dstCap, 0, 0, result, nullptr);
+}
+
+int plz4hip_xxh32_batch(plz4hip_ctx* c, int n, const void* const* buf, const int32_t* len, uint32_t* out)
+{
+    if (!c || n < 0 || (n && (!buf || !len || !out))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_xxh32_batch: bad argument");
+    return host_codec(c, 4, n, buf, len, nullptr, nullptr, 0, 0, (int32_t*)out, nullptr);
+}
+
+int plz4hip_encode_records(plz4hip_ctx* c, int nBlocks, const void* const* src, const int32_t* srcLen,
+                           int bsz, int level, int blockChecksum, void* const* rec, int32_t* recLen)
+{
+    if (!c || nBlocks < 0 || bsz <= 0 || (nBlocks && (!src || !srcLen || !rec || !recLen))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_encode_records: bad argument");
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    for (int i = 0; i < nBlocks; ++i) if (srcLen[i] > bsz) return fail(c, PLZ4HIP_E_ARG, "source block larger than block size");
+    return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr);
+}
+
+int plz4hip_decode_records(plz4hip_ctx* c, int nBlocks, const void* const* rec, const int32_t* recLen,
+                           int bsz, int blockChecksum, void* const* dst, int32_t* result, int32_t* status)
+{
+    if (!c || nBlocks < 0 || bsz <= 0 || (nBlocks && (!rec || !recLen || !dst || !result || !status))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_decode_records: bad argument");
+    for (int i = 0; i < nBlocks; ++i) if (recLen[i] < 4) return fail(c, PLZ4HIP_E_ARG, "record shorter than its size word");
+    return host_codec(c, 3, nBlocks, rec, recLen, dst, nullptr, bsz, blockChecksum, result, status);
+}
+
+}  // extern "C"

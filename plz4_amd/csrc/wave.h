@@ -1,0 +1,92 @@
+// wave.h -- the only abstraction layer in the device code.
+//
+// The codec kernels are written for ONE 64-lane CDNA4 wavefront per LZ4 block: wave-uniform control
+// flow (block cursor, output cursor, parser state live in scalar registers) with short SPMD sections
+// in which the 64 lanes probe / compare / copy in parallel and vote with a 64-bit ballot.
+//
+// The same source is compiled twice:
+//   * by hipcc for gfx950 -- the product (LANES(...) is the implicit SIMT lane, BALLOT is v_cmp+s_mov
+//     of the exec-wide mask, RL is v_readlane_b32, UNI is v_readfirstlane_b32);
+//   * by g++ with -DPLZ4_EMU for tests/emu -- a lane-emulation harness in which LANES(...) is a
+//     for-loop over 64 lanes and per-lane variables are 64-element arrays.  That build exists so the
+//     kernel LOGIC can be unit-tested on a machine without a GPU; it is test infrastructure, it is
+//     never loaded by plz4_amd and it is not a CPU fallback.
+//
+// Conventions: LV(T, x) declares a per-lane variable, accessed as x[I_]; everything else is
+// wave-uniform.  Code inside LANES(...) may diverge freely; code outside must be uniform.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(PLZ4_EMU)
+// ---------------------------------------------------------------- CPU lane emulation (tests only)
+#include <string.h>
+#define DEV            static inline
+#define LV(T, x)       T x[64]
+#define I_             lane_
+#define LANE           lane_
+#define LANES(...)     for (int lane_ = plz4_emu_first(); lane_ != plz4_emu_end(); lane_ += plz4_emu_step()) { __VA_ARGS__ }
+#define BALLOT(c)      ([&]() { uint64_t m_ = 0; for (int lane_ = 0; lane_ < 64; ++lane_) if (c) m_ |= 1ull << lane_; return m_; }())
+#define RL(x, w)       ((x)[(w)])
+#define UNI(x)         (x)
+#define WAVE_FENCE()   do {} while (0)
+#define LDS_FENCE()    do {} while (0)
+// Same-address LDS store conflicts inside one instruction are resolved in an unspecified lane order on
+// hardware; the emulation can run lanes ascending or descending so tests cover both resolutions.
+extern int plz4_emu_descending;
+static inline int plz4_emu_first() { return plz4_emu_descending ? 63 : 0; }
+static inline int plz4_emu_end()   { return plz4_emu_descending ? -1 : 64; }
+static inline int plz4_emu_step()  { return plz4_emu_descending ? -1 : 1; }
+#else
+// ---------------------------------------------------------------- gfx950
+#include <hip/hip_runtime.h>
+#define DEV            __device__ __forceinline__
+#define LV(T, x)       T x[1]
+#define I_             0
+#define LANE           ((int)(threadIdx.x & 63u))
+#define LANES(...)     { __VA_ARGS__ }
+#define BALLOT(c)      ((uint64_t)__ballot((c)))
+#define RL(x, w)       plz4_readlane((x)[0], (w))
+#define UNI(x)         plz4_readfirstlane((x))
+// Same-wave producer/consumer through memory needs no cache action on CDNA (one TCP, in-order VMEM
+// queue); the fence only stops the compiler from reordering the accesses.
+#define WAVE_FENCE()   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+#define LDS_FENCE()    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+
+__device__ __forceinline__ uint32_t plz4_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ int      plz4_readlane(int v, int l)      { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint64_t plz4_readlane(uint64_t v, int l)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t plz4_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int      plz4_readfirstlane(int v)      { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint8_t  plz4_readfirstlane(uint8_t v)  { return (uint8_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint16_t plz4_readfirstlane(uint16_t v) { return (uint16_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t plz4_readfirstlane(uint64_t v)
+{
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+#endif
+
+// ---------------------------------------------------------------- unaligned little-endian access
+// gfx950 runs with unaligned-access-mode on, so these become single global_load/store_{ushort,dword,dwordx2,dwordx4}.
+typedef uint16_t __attribute__((aligned(1), may_alias)) u16u_t;
+typedef uint32_t __attribute__((aligned(1), may_alias)) u32u_t;
+typedef uint64_t __attribute__((aligned(1), may_alias)) u64u_t;
+struct __attribute__((packed, may_alias)) v16u_t { uint32_t w[4]; };
+
+DEV uint16_t ld16u(const uint8_t* p) { return *(const u16u_t*)p; }
+DEV uint32_t ld32u(const uint8_t* p) { return *(const u32u_t*)p; }
+DEV uint64_t ld64u(const uint8_t* p) { return *(const u64u_t*)p; }
+DEV void     st16u(uint8_t* p, uint16_t v) { *(u16u_t*)p = v; }
+DEV void     st32u(uint8_t* p, uint32_t v) { *(u32u_t*)p = v; }
+
+DEV int ctz64(uint64_t v) { return __builtin_ctzll(v); }
+DEV uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+template <class T> DEV T min_(T a, T b) { return a < b ? a : b; }
+template <class T> DEV T max_(T a, T b) { return a > b ? a : b; }

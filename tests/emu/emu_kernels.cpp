@@ -1,0 +1,27 @@
+// Lane-emulation harness: compiles plz4_amd/csrc/lz4_device.inl (the SAME source hipcc builds for gfx950)
+// with -DPLZ4_EMU so that the kernel logic can be checked against the oracle on a machine without a GPU.
+// Test infrastructure only: built into tests/emu/_build/, never loaded by plz4_amd, not a CPU fallback.
+#define PLZ4_EMU 1
+#include "../../plz4_amd/csrc/lz4_device.inl"
+#include <stdlib.h>
+
+int plz4_emu_descending = 0;
+
+extern "C" {
+
+void emu_set_descending(int d) { plz4_emu_descending = d; }
+
+int emu_encode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
+{
+    static thread_local uint32_t lds[plz4::kHashBytes / 4];
+    return plz4::wave_encode_block(src, n, dst, cap, lds);
+}
+
+int emu_decode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
+{
+    return plz4::wave_decode_block(src, n, dst, cap);
+}
+
+uint32_t emu_xxh32(const uint8_t* p, int n) { return plz4::wave_xxh32(p, n); }
+
+}

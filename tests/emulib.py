@@ -1,0 +1,51 @@
+"""ctypes binding for the lane-emulation build of the device code (tests/emu/emu_kernels.cpp).
+Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from orclib import ROOT, _ptr, u8p
+
+EMU_SRC = os.path.join(ROOT, "tests", "emu", "emu_kernels.cpp")
+EMU_SO = os.path.join(ROOT, "tests", "emu", "_build", "libemu.so")
+DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "wave.h")]
+
+
+def build_emu():
+    newest = max(os.path.getmtime(p) for p in [EMU_SRC] + DEV_SRCS)
+    if (not os.path.exists(EMU_SO)) or os.path.getmtime(EMU_SO) < newest:
+        os.makedirs(os.path.dirname(EMU_SO), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-parameter",
+                               "-o", EMU_SO, EMU_SRC])
+
+
+class Emu:
+    def __init__(self):
+        build_emu()
+        L = self.L = C.CDLL(EMU_SO)
+        L.emu_encode_block.restype = C.c_int
+        L.emu_encode_block.argtypes = [u8p, C.c_int, u8p, C.c_int]
+        L.emu_decode_block.restype = C.c_int
+        L.emu_decode_block.argtypes = [u8p, C.c_int, u8p, C.c_int]
+        L.emu_xxh32.restype = C.c_uint32
+        L.emu_xxh32.argtypes = [u8p, C.c_int]
+
+    def set_descending(self, d: bool):
+        self.L.emu_set_descending(int(d))
+
+    def compress_fast(self, src: np.ndarray, cap: int):
+        dst = np.empty(max(cap, 1) + 32, dtype=np.uint8)
+        r = int(self.L.emu_encode_block(_ptr(src), src.size, _ptr(dst), cap))
+        return r, dst[:max(r, 0)]
+
+    def decompress_safe(self, src: np.ndarray, cap: int):
+        dst = np.zeros(max(cap, 1) + 32, dtype=np.uint8)
+        r = int(self.L.emu_decode_block(_ptr(src), src.size, _ptr(dst), cap))
+        return r, dst[:max(r, 0)]
+
+    def xxh32(self, a: np.ndarray) -> int:
+        return int(self.L.emu_xxh32(_ptr(a) if a.size else C.cast(None, u8p), a.size))

@@ -1,0 +1,130 @@
+"""The device code (plz4_amd/csrc/lz4_device.inl), compiled for CPU by the lane-emulation harness, against the
+oracle.  Same source hipcc builds for gfx950; this covers the kernel LOGIC without a GPU (the GPU parity tests
+in test_gpu_parity.py run the real thing).  Both resolutions of same-slot LDS store conflicts are exercised."""
+import numpy as np
+import pytest
+
+import corpus
+from plz4_amd import synth
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emulib import Emu
+    return Emu()
+
+
+@pytest.fixture(params=[False, True], ids=["lanes_asc", "lanes_desc"])
+def emu_o(emu, request):
+    emu.set_descending(request.param)
+    yield emu
+    emu.set_descending(False)
+
+
+def _enc(orc, emu, src, cap):
+    a, da = orc.compress_fast(src, cap)
+    b, db = emu.compress_fast(src, cap)
+    assert a == b, (src.size, cap, a, b)
+    assert np.array_equal(da, db), (src.size, cap)
+
+
+def test_emu_encode_small(orc, emu_o):
+    for name, src in corpus.small_cases():
+        n = src.size
+        for cap in (orc.bound(n), n, max(n - 1, 0), n + 8):
+            _enc(orc, emu_o, src, cap)
+
+
+def test_emu_encode_64k_boundary(orc, emu_o):
+    for name, src in corpus.block_cases_64k():
+        for cap in (orc.bound(src.size), src.size):
+            _enc(orc, emu_o, src, cap)
+
+
+def test_emu_encode_structured(orc, emu_o):
+    for seed in range(25):
+        n = int(np.random.default_rng(seed).integers(13, 200000))
+        src = corpus.structured(n, seed)
+        _enc(orc, emu_o, src, n)
+        _enc(orc, emu_o, src, orc.bound(n))
+
+
+def test_emu_encode_limited_threshold(orc, emu):
+    src = corpus.structured(5000, 2)
+    full, _ = orc.compress_fast(src, orc.bound(src.size))
+    for cap in range(max(full - 30, 0), full + 30):
+        _enc(orc, emu, src, cap)
+
+
+@pytest.mark.parametrize("kind", ["T", "R", "Z", "M"])
+def test_emu_encode_4m(orc, emu, kind):
+    bsz = 4 << 20
+    data = synth.make(kind, bsz + 70001, bsz)
+    _enc(orc, emu, data[:bsz], bsz)
+    _enc(orc, emu, data[bsz:], bsz)
+
+
+def _dec(orc, emu, comp, cap):
+    a, da = orc.decompress_safe(comp, cap)
+    b, db = emu.decompress_safe(comp, cap)
+    assert a == b, (comp.size, cap, a, b)
+    if a >= 0:
+        assert np.array_equal(da, db)
+    return a
+
+
+def test_emu_decode_valid(orc, emu):
+    for name, src in corpus.small_cases() + corpus.block_cases_64k():
+        n = src.size
+        c, comp = orc.compress_fast(src, orc.bound(n))
+        comp = np.ascontiguousarray(comp)
+        for cap in (n, n + 8, n + 64, max(n - 1, 0), max(n - 13, 0)):
+            _dec(orc, emu, comp, cap)
+
+
+def test_emu_decode_corrupt(orc, emu):
+    rng = np.random.default_rng(11)
+    nbad = 0
+    for seed in range(20):
+        n = int(rng.integers(20, 20000))
+        src = corpus.structured(n, seed + 500)
+        c, comp = orc.compress_fast(src, orc.bound(n))
+        for trial in range(40):
+            bad = comp.copy()
+            k = int(rng.integers(0, 4))
+            if k == 0:
+                bad = bad[:int(rng.integers(1, bad.size))]
+            elif k == 1:
+                i = int(rng.integers(0, bad.size)); bad[i] ^= 1 << int(rng.integers(0, 8))
+            elif k == 2:
+                i = int(rng.integers(0, bad.size)); bad[i] = 0xFF
+            else:
+                i = int(rng.integers(0, bad.size)); bad[i:i + 2] = 0
+            for cap in (n, n + 8):
+                nbad += _dec(orc, emu, np.ascontiguousarray(bad), cap) < 0
+    assert nbad > 300
+
+
+def test_emu_decode_special(orc, emu):
+    blk = np.array([0x14, 0x41, 0x00, 0x00] + [0x50, 1, 2, 3, 4, 5], dtype=np.uint8)   # offset 0 -> zero fill
+    for cap in (14, 15, 100):
+        _dec(orc, emu, blk, cap)
+    _dec(orc, emu, np.array([0], dtype=np.uint8), 0)
+    _dec(orc, emu, np.array([0], dtype=np.uint8), 10)
+    _dec(orc, emu, np.array([0, 0], dtype=np.uint8), 0)
+
+
+def test_emu_decode_4m(orc, emu):
+    bsz = 4 << 20
+    for kind in ("T", "Z", "M"):
+        src = synth.make(kind, bsz, bsz)
+        c, comp = orc.compress_fast(src, orc.bound(bsz))
+        n, out = emu.decompress_safe(np.ascontiguousarray(comp), bsz + 8)     # plz4 decodes into bsz+8 (blk/blk.go:51-53)
+        assert n == bsz and np.array_equal(out, src)
+
+
+def test_emu_xxh32(orc, emu):
+    rng = np.random.default_rng(3)
+    for n in list(range(0, 70)) + [127, 128, 129, 255, 1000, 4096, 100003, 1 << 20]:
+        a = rng.integers(0, 256, size=n, dtype=np.uint8)
+        assert emu.xxh32(a) == orc.xxh32(a), n
