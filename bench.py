@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: MiB/s of plaintext through encode + decode of 4 MiB independent
+LZ4 blocks (level 1, block checksum on, content checksum off: configs[1]/[2]), with the % of the HBM roofline of
+the dominant kernel and plz4's CPU path timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--kind T|R|Z|M]
+    N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL), see the contract in the task statement.
+
+One step = one pass of the hot path over one batch that is already resident in HBM:
+    encode kernel (B blocks -> staged records, fused xxh32) -> scan + compaction into the frame body
+    [N > 1: RCCL gather of the bodies to rank 0 + interleave into the final frame body]
+    -> decode kernel (frame body -> B plaintext blocks, checksum verified).
+Blocks are independent, so ranks share nothing on the data path (weak scaling: B blocks per GPU); block i of the
+global stream lives on rank i mod N.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BSZ = 4 << 20
+POOL_BLOCKS = 16            # 64 MiB of unique T text generated on the host, tiled (rotated) to B blocks on the device
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(pool: np.ndarray, seconds: float = 12.0):
+    """plz4's CPU path for the same per-block work (LZ4_compress_fast cap=bsz -> stored fallback -> xxh32, then
+    verify xxh32 + LZ4_decompress_safe into bsz+8), one block per task on all host cores.  Uses the compiled
+    reference liblz4 (oracle/_ref) when present, else the oracle restatement."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib
+    orc = orclib.Oracle()
+    kind = "port"
+    enc = lambda s, d: orc.L.orc_compress_fast(s, BSZ, d, BSZ)
+    dec = lambda s, n, d: orc.L.orc_decompress_safe(s, n, d, BSZ + 8)
+    if os.path.exists(orclib.REF_SO):
+        ref = orclib.Ref()
+        kind = "reference"
+        enc = lambda s, d: ref.L.LZ4_compress_fast(s, d, BSZ, BSZ, 1)
+        dec = lambda s, n, d: ref.L.LZ4_decompress_safe(s, d, n, BSZ + 8)
+    cores = os.cpu_count() or 1
+    nblk = pool.size // BSZ
+    srcs = [np.ascontiguousarray(pool[i * BSZ:(i + 1) * BSZ]) for i in range(nblk)]
+    comp = [np.empty(BSZ + 8, dtype=np.uint8) for _ in range(nblk)]
+    outs = [np.empty(BSZ + 8, dtype=np.uint8) for _ in range(cores)]
+    clen = [0] * nblk
+    u8p = orclib.u8p
+
+    def do_enc(i):
+        s = srcs[i].ctypes.data_as(u8p); d = comp[i].ctypes.data_as(u8p)
+        c = enc(s, d)
+        if c == 0:
+            comp[i][:BSZ] = srcs[i]; c = BSZ
+        clen[i] = c
+        return orc.L.orc_xxh32(d, c)
+
+    def do_dec(args):
+        i, slot = args
+        d = comp[i].ctypes.data_as(u8p)
+        orc.L.orc_xxh32(d, clen[i])
+        return dec(d, clen[i], outs[slot].ctypes.data_as(u8p))
+
+    def timed(fn, items, threads):
+        with ThreadPoolExecutor(threads) as ex:
+            t0 = time.perf_counter(); list(ex.map(fn, items)); return time.perf_counter() - t0
+
+    timed(do_enc, range(nblk), cores)                                        # warm-up pass
+    t_enc = t_dec = 0.0; passes = 0
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < seconds:
+        t_enc += timed(do_enc, range(nblk), cores)
+        t_dec += timed(do_dec, [(i, i % cores) for i in range(nblk)], cores)
+        passes += 1
+    mib = passes * nblk * BSZ / 2**20
+    t1e = timed(do_enc, range(min(nblk, 4)), 1); t1d = timed(do_dec, [(i, 0) for i in range(min(nblk, 4))], 1)
+    one = min(nblk, 4) * BSZ / 2**20
+    return {
+        "value": round(mib / (t_enc + t_dec), 1), "unit": "MiB/s", "cores": cores, "kind": kind,
+        "sample": "%d passes over %d x 4MiB T blocks (%.0f MiB), one block per task on %d threads; "
+                  "enc %.0f MiB/s, dec %.0f MiB/s; 1 thread: enc %.0f, dec %.0f MiB/s; LZ4 = %s, xxh32 = oracle C"
+                  % (passes, nblk, mib, cores, mib / t_enc, mib / t_dec, one / t1e, one / t1d,
+                     "vendored liblz4 1.10.0 (oracle/_ref)" if kind == "reference" else "oracle restatement"),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("PLZ4_BENCH_BLOCKS", "2560")),
+                    help="4 MiB blocks per GPU per step")
+    ap.add_argument("--kind", default="T")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log("note: WORLD_SIZE=%d but --gpus %d; using WORLD_SIZE" % (world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    from plz4_amd import synth
+    from plz4_amd._native import Engine
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    eng = Engine(local)
+
+    B = args.blocks
+    S = B * BSZ
+    t0 = time.time()
+    pool = synth.make(args.kind, POOL_BLOCKS * BSZ, BSZ)
+    d_pool = torch.from_numpy(pool).to(dev)
+    d_src = torch.empty(S, dtype=torch.uint8, device=dev)
+    psz = d_pool.numel()
+    for r in range((S + psz - 1) // psz):                                    # rotated replicas: every block distinct
+        g = rank + world * r                                                 # global replica id (block i -> rank i mod N)
+        shift = (g * 1000003) % psz
+        rep = torch.roll(d_pool, -shift) if shift else d_pool
+        lo = r * psz; n = min(psz, S - lo)
+        d_src[lo:lo + n] = rep[:n]
+    del rep
+    stride = eng.stage_stride(BSZ)
+    d_stage = torch.empty(B * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    d_body = torch.empty(B * (BSZ + 8), dtype=torch.uint8, device=dev)
+    d_out = torch.empty(S, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(B, dtype=torch.int32, device=dev)
+    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    log("rank %d: %d blocks (%.1f GiB) ready in %.1fs" % (rank, B, S / 2**30, time.time() - t0))
+
+    gather = {}
+
+    def frame_gather():
+        """N > 1: rank 0 owns the io.Writer.  All-gather the record sizes (tiny), send every body to rank 0 over
+        xGMI (RCCL send/recv), interleave there: global block g = j*N + r is record j of rank r."""
+        lens = torch.empty(world * B, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(lens, d_len)
+        lens = lens.view(world, B)
+        totals = lens.sum(dim=1, dtype=torch.int64)
+        if rank == 0:
+            tot = totals.cpu().tolist()
+            cap = max(tot)
+            if gather.get("cap", 0) < cap:
+                gather["buf"] = torch.empty((world - 1) * cap, dtype=torch.uint8, device=dev); gather["cap"] = cap
+                gather["frame"] = torch.empty(int(sum(tot) * 1.02) + (1 << 20), dtype=torch.uint8, device=dev)
+            cap = gather["cap"]
+            reqs = [dist.irecv(gather["buf"][(r - 1) * cap:(r - 1) * cap + tot[r]], src=r) for r in range(1, world)]
+            # offsets while the transfers fly: destination = exclusive scan in global (interleaved) order
+            inter = lens.t().contiguous().view(-1)                                  # [j*N + r]
+            dst_off = torch.cumsum(inter.to(torch.int64), 0) - inter
+            dst_off = dst_off.view(B, world).t().contiguous()                       # [r][j]
+            for r in range(world):
+                src_off = torch.cumsum(lens[r].to(torch.int64), 0) - lens[r]
+                if r == 0:
+                    eng.dev_scatter_records(d_body.data_ptr(), src_off.data_ptr(), lens[0].contiguous().data_ptr(),
+                                            dst_off[0].data_ptr(), B, BSZ + 8, gather["frame"].data_ptr(),
+                                            gather["frame"].numel(), stream)
+            for q in reqs:
+                q.wait()
+            for r in range(1, world):
+                src_off = torch.cumsum(lens[r].to(torch.int64), 0) - lens[r] + (r - 1) * cap
+                lr = lens[r].contiguous()
+                eng.dev_scatter_records(gather["buf"].data_ptr(), src_off.data_ptr(), lr.data_ptr(),
+                                        dst_off[r].data_ptr(), B, BSZ + 8, gather["frame"].data_ptr(),
+                                        gather["frame"].numel(), stream)
+        else:
+            total = int(totals[rank].item())
+            dist.send(d_body[:total], dst=0)
+
+    def step(ev=None):
+        if ev: ev[0].record()
+        eng.dev_encode_records(d_src.data_ptr(), S, BSZ, True, d_stage.data_ptr(), d_len.data_ptr(), stream)
+        if ev: ev[1].record()
+        eng.dev_compact_records(d_stage.data_ptr(), stride, d_len.data_ptr(), B, d_off.data_ptr(), d_body.data_ptr(),
+                                d_body.numel(), stream)
+        if ev: ev[2].record()
+        if world > 1:
+            frame_gather()
+        if ev: ev[3].record()
+        eng.dev_decode_records(d_body.data_ptr(), d_off.data_ptr(), B, BSZ, True, d_out.data_ptr(), BSZ, BSZ,
+                               d_res.data_ptr(), d_st.data_ptr(), stream)
+        if ev: ev[4].record()
+
+    # ---- correctness gate before any timing: round trip bit-exact, every block status OK, records == oracle
+    d_out.zero_()
+    step()
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum().item()) == 0, "decode status != OK"
+    assert int(d_res.to(torch.int64).sum().item()) == S, "decoded size mismatch"
+    assert torch.equal(d_out, d_src), "round trip mismatch"
+    C_bytes = int(d_off[-1].item())
+    if rank == 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        orc = orclib.Oracle()
+        offs = d_off[:3].cpu().tolist()
+        for i in range(2):
+            want = orc.block_record(d_src[i * BSZ:(i + 1) * BSZ].cpu().numpy(), BSZ, True)
+            got = d_body[offs[i]:offs[i + 1]].cpu().numpy()
+            assert np.array_equal(want, got), "record %d differs from the oracle" % i
+        log("parity gate ok: round trip exact, 2 records == oracle, stored/plain ratio %.4f" % (C_bytes / S))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(evs[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    seg = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in evs])     # ms: enc, compact, gather, dec
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        enc_ms, cmp_ms, gat_ms, dec_ms = seg.mean(axis=0).tolist()
+        mib = S / 2**20
+        ach_enc = (S + C_bytes) / (enc_ms * 1e-3) / 1e9
+        ach_dec = (S + C_bytes) / (dec_ms * 1e-3) / 1e9
+        out = {
+            "metric": "MiB/s enc+dec, 4MiB independent blocks, level 1, block-checksum on",
+            "value": round(world * mib / (ms_step * 1e-3), 1),
+            "unit": "MiB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]+[2]: %d x 4MiB independent blocks per GPU of synthetic %s text "
+                                   "(64 MiB PCG64/Zipf pool, rotated replicas), level 1, block checksum on, content "
+                                   "checksum off; step = encode->frame body->decode, inputs resident in HBM"
+                                   % (B, args.kind),
+                       "blocks_per_gpu": B, "block_bytes": BSZ, "stored_ratio": round(C_bytes / S, 4),
+                       "sharding": "block i -> rank i mod N" if world > 1 else "single GPU"},
+            "enc_MiBps_per_gpu": round(mib / (enc_ms * 1e-3), 1),
+            "dec_MiBps_per_gpu": round(mib / (dec_ms * 1e-3), 1),
+            "ms": {"encode_kernel": round(enc_ms, 3), "scan_compact": round(cmp_ms, 3),
+                   "frame_gather": round(gat_ms, 3), "decode_kernel": round(dec_ms, 3)},
+            "roofline": {"bound": "hbm", "kernel": "k_encode_rec", "achieved": round(ach_enc, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(ach_enc / HBM_PEAK_GBS, 5), "traffic": None},
+            "roofline_decode": {"bound": "hbm", "kernel": "k_decode_rec", "achieved": round(ach_dec, 2),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_dec / HBM_PEAK_GBS, 5),
+                                "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pool)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

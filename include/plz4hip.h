@@ -101,22 +101,32 @@ int plz4hip_decode_records(plz4hip_ctx* ctx, int nBlocks,
 
 /* ---------------------------------------------------------------------------------------------------------
  * C. Device-resident pipeline (bench.py, GPU-to-GPU producers).  Every pointer below is a DEVICE pointer
- *    on ctx's device; work is enqueued on `stream` (a hipStream_t, NULL = the ctx's own stream) and the call
- *    returns without synchronising.  Layout:
+ *    on ctx's device; work is enqueued on `stream` (a hipStream_t; NULL is HIP's default/null stream, as for any
+ *    hip*Async call) and the call returns without synchronising.  Layout:
  *      src     plaintext, block i = src[i*bsz, min((i+1)*bsz, srcBytes))          nBlocks = ceil(srcBytes/bsz)
  *      stage   nBlocks records at stride plz4hip_dev_stage_stride(bsz)             (scratch)
  *      recLen  int32[nBlocks]   record i length (4 + payload + 4 if checksums)
  *      recOff  int64[nBlocks+1] exclusive prefix sum of recLen (recOff[nBlocks] = body bytes)
  *      body    the records, compacted back to back: exactly the frame's block section
- *    plz4hip_dev_encode_records = encode kernel -> scan -> compaction.  body may be NULL to skip compaction.
+ *    plz4hip_dev_encode_records  : the encode kernel; fills stage + recLen.
+ *    plz4hip_dev_compact_records : exclusive scan of recLen -> recOff, then moves every record to body+recOff[i];
+ *                                  records that would end past bodyCap are skipped (recOff[nBlocks] > bodyCap tells).
+ *    plz4hip_dev_scatter_records : generic record mover, dst+dstOff[k] <- src+srcOff[k] (len[k] bytes); used by the
+ *                                  multi-GPU frame assembly, where the owner rank interleaves the bodies it
+ *                                  received from the other ranks (block i lives on rank i mod G).
  *    plz4hip_dev_decode_records reads records at body+recOff[i] and writes block i at dst + i*dstStride
  *    (capacity dstCap, bsz+8 in the reference); result/status as in B.
  * ------------------------------------------------------------------------------------------------------- */
 int64_t plz4hip_dev_stage_stride(int bsz);
 
 int plz4hip_dev_encode_records(plz4hip_ctx* ctx, const void* src, int64_t srcBytes, int bsz, int level,
-                               int blockChecksum, void* stage, int32_t* recLen, int64_t* recOff,
-                               void* body, int64_t bodyCap, void* stream);
+                               int blockChecksum, void* stage, int32_t* recLen, void* stream);
+
+int plz4hip_dev_compact_records(plz4hip_ctx* ctx, const void* stage, int64_t stageStride, const int32_t* recLen,
+                                int nBlocks, int64_t* recOff, void* body, int64_t bodyCap, void* stream);
+
+int plz4hip_dev_scatter_records(plz4hip_ctx* ctx, const void* src, const int64_t* srcOff, const int32_t* len,
+                                const int64_t* dstOff, int n, int maxLen, void* dst, int64_t dstCap, void* stream);
 
 int plz4hip_dev_decode_records(plz4hip_ctx* ctx, const void* body, const int64_t* recOff, int nBlocks,
                                int bsz, int blockChecksum, void* dst, int64_t dstStride, int dstCap,

@@ -17,7 +17,8 @@ SYMBOLS = [
     "plz4hip_abi_version", "plz4hip_device_count", "plz4hip_ctx_create", "plz4hip_ctx_destroy",
     "plz4hip_last_error", "plz4hip_compress_bound", "plz4hip_compress_batch", "plz4hip_decompress_batch",
     "plz4hip_xxh32_batch", "plz4hip_encode_records", "plz4hip_decode_records", "plz4hip_dev_stage_stride",
-    "plz4hip_dev_encode_records", "plz4hip_dev_decode_records", "plz4hip_dev_compress", "plz4hip_dev_decompress",
+    "plz4hip_dev_encode_records", "plz4hip_dev_compact_records", "plz4hip_dev_scatter_records",
+    "plz4hip_dev_decode_records", "plz4hip_dev_compress", "plz4hip_dev_decompress",
     "plz4hip_dev_resident_waves",
 ]
 
@@ -74,7 +75,11 @@ def load():
     L.plz4hip_dev_stage_stride.restype = C.c_int64
     L.plz4hip_dev_stage_stride.argtypes = [C.c_int]
     L.plz4hip_dev_encode_records.restype = C.c_int
-    L.plz4hip_dev_encode_records.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int64, vp]
+    L.plz4hip_dev_encode_records.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.plz4hip_dev_compact_records.restype = C.c_int
+    L.plz4hip_dev_compact_records.argtypes = [vp, vp, C.c_int64, vp, C.c_int, vp, vp, C.c_int64, vp]
+    L.plz4hip_dev_scatter_records.restype = C.c_int
+    L.plz4hip_dev_scatter_records.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int64, vp]
     L.plz4hip_dev_decode_records.restype = C.c_int
     L.plz4hip_dev_decode_records.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp, vp, vp]
     L.plz4hip_dev_compress.restype = C.c_int
@@ -185,10 +190,17 @@ class Engine:
         return res, st, [d[:max(int(r), 0)] for d, r in zip(dsts, res)]
 
     # ---- C. device-resident pipeline (raw device pointers; torch tensors supply .data_ptr())
-    def dev_encode_records(self, src_ptr, src_bytes, bsz, block_checksum, stage_ptr, reclen_ptr, recoff_ptr,
-                           body_ptr, body_cap, stream=0, level: int = 1):
+    def dev_encode_records(self, src_ptr, src_bytes, bsz, block_checksum, stage_ptr, reclen_ptr, stream=0, level: int = 1):
         self._chk(self.L.plz4hip_dev_encode_records(self.h, src_ptr, src_bytes, bsz, level, int(block_checksum), stage_ptr,
-                                                    reclen_ptr, recoff_ptr, body_ptr, body_cap, stream))
+                                                    reclen_ptr, stream))
+
+    def dev_compact_records(self, stage_ptr, stage_stride, reclen_ptr, nblocks, recoff_ptr, body_ptr, body_cap, stream=0):
+        self._chk(self.L.plz4hip_dev_compact_records(self.h, stage_ptr, stage_stride, reclen_ptr, nblocks, recoff_ptr,
+                                                     body_ptr, body_cap, stream))
+
+    def dev_scatter_records(self, src_ptr, srcoff_ptr, len_ptr, dstoff_ptr, n, max_len, dst_ptr, dst_cap, stream=0):
+        self._chk(self.L.plz4hip_dev_scatter_records(self.h, src_ptr, srcoff_ptr, len_ptr, dstoff_ptr, n, max_len, dst_ptr,
+                                                     dst_cap, stream))
 
     def dev_decode_records(self, body_ptr, recoff_ptr, nblocks, bsz, block_checksum, dst_ptr, dst_stride, dst_cap,
                            result_ptr, status_ptr, stream=0):

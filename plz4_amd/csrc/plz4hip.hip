@@ -157,20 +157,23 @@ __global__ __launch_bounds__(1024) void k_scan(const int32_t* __restrict__ len, 
     if (t == 1023) off[n] = part[1023];
 }
 
-// Records from the staging area (fixed stride) to their final, back-to-back place in the frame body.
-// grid = (nBlocks, slices); 256 threads copy 16 bytes each per step (unaligned on both sides is fine on gfx950).
-__global__ __launch_bounds__(256) void k_compact(const uint8_t* __restrict__ stage, int64_t stride,
-                                                 const int32_t* __restrict__ len, const int64_t* __restrict__ off,
-                                                 uint8_t* __restrict__ body)
+// Record mover: dst + dstOff[i] <- src + (srcOff ? srcOff[i] : i*stride), len[i] bytes.  Compaction of the staging
+// area into the frame body is the srcOff == nullptr case.  grid = (n, slices); 256 threads move 16 bytes each per
+// step (unaligned on both sides is fine on gfx950: global_load/store_dwordx4).
+__global__ __launch_bounds__(256) void k_move_records(const uint8_t* __restrict__ src, const int64_t* __restrict__ srcOff,
+                                                      int64_t stride, const int32_t* __restrict__ len,
+                                                      const int64_t* __restrict__ dstOff, uint8_t* __restrict__ dst,
+                                                      int64_t dstCap)
 {
     const int      i = blockIdx.x;
     const int      n = len[i];
-    const uint8_t* s = stage + (int64_t)i * stride;
-    uint8_t*       d = body + off[i];
+    if (dstOff[i] + n > dstCap) return;      // caller sees the overflow as recOff[n] > bodyCap
+    const uint8_t* s = src + (srcOff ? srcOff[i] : (int64_t)i * stride);
+    uint8_t*       d = dst + dstOff[i];
     const int full = n & ~15;
     for (int p = (blockIdx.y * 256 + threadIdx.x) * 16; p < full; p += gridDim.y * 256 * 16)
         *(v16u_t*)(d + p) = *(const v16u_t*)(s + p);
-    if (blockIdx.y == 0 && threadIdx.x < (n - full)) d[full + threadIdx.x] = s[full + threadIdx.x];
+    if (blockIdx.y == 0 && (int)threadIdx.x < (n - full)) d[full + threadIdx.x] = s[full + threadIdx.x];
 }
 
 }  // namespace
@@ -311,7 +314,7 @@ int plz4hip_dev_compress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t s
     if (nBlocks == 0) return PLZ4HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
     CodecArgs a{};
     a.src = (const uint8_t*)src; a.srcStride = srcStride; a.srcLen = srcLen;
@@ -329,7 +332,7 @@ int plz4hip_dev_decompress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t
     if (nBlocks == 0) return PLZ4HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
     CodecArgs a{};
     a.src = (const uint8_t*)src; a.srcStride = srcStride; a.srcLen = srcLen;
@@ -341,8 +344,7 @@ int plz4hip_dev_decompress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t
 }
 
 int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes, int bsz, int level,
-                               int blockChecksum, void* stage, int32_t* recLen, int64_t* recOff,
-                               void* body, int64_t bodyCap, void* stream)
+                               int blockChecksum, void* stage, int32_t* recLen, void* stream)
 {
     if (!c || srcBytes < 0 || bsz <= 0 || !stage || !recLen) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_encode_records: bad argument");
     if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
@@ -350,28 +352,51 @@ int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes
     if (nb64 > 0x7FFFFFFF) return fail(c, PLZ4HIP_E_ARG, "too many blocks");
     const int nBlocks = (int)nb64;
     if (nBlocks == 0) return PLZ4HIP_OK;
-    if (body && (!recOff || bodyCap < srcBytes + (int64_t)nBlocks * 8)) return fail(c, PLZ4HIP_E_ARG, "body buffer too small (need srcBytes + 8*nBlocks)");
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
-    const int64_t stride = plz4hip_dev_stage_stride(bsz);
     CodecArgs a{};
     a.src = (const uint8_t*)src; a.srcStride = bsz; a.srcBytes = srcBytes; a.bsz = bsz;
-    a.dst = (uint8_t*)stage; a.dstStride = stride;
+    a.dst = (uint8_t*)stage; a.dstStride = plz4hip_dev_stage_stride(bsz);
     a.result = recLen; a.queue = q; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
     hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
     HIPCHK(c, hipGetLastError());
-    if (recOff) {
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, recLen, recOff, nBlocks);
-        HIPCHK(c, hipGetLastError());
-    }
+    return PLZ4HIP_OK;
+}
+
+static int move_slices(int maxLen) { const int s = (maxLen + 256 * 16 * 8 - 1) / (256 * 16 * 8); return s < 1 ? 1 : s; }
+
+int plz4hip_dev_compact_records(plz4hip_ctx* c, const void* stage, int64_t stageStride, const int32_t* recLen,
+                                int nBlocks, int64_t* recOff, void* body, int64_t bodyCap, void* stream)
+{
+    if (!c || nBlocks < 0 || !stage || !recLen || !recOff || stageStride <= 0) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_compact_records: bad argument");
+    if (body && bodyCap <= 0) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_compact_records: bodyCap");
+    if (nBlocks == 0) return PLZ4HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, recLen, recOff, nBlocks);
+    HIPCHK(c, hipGetLastError());
     if (body) {
-        const int slices = (bsz + 8 + 256 * 16 * 8 - 1) / (256 * 16 * 8);     // ~8 steps per thread on a full block
-        hipLaunchKernelGGL(k_compact, dim3(nBlocks, slices < 1 ? 1 : slices), dim3(256), 0, s,
-                           (const uint8_t*)stage, stride, recLen, recOff, (uint8_t*)body);
+        hipLaunchKernelGGL(k_move_records, dim3(nBlocks, move_slices((int)stageStride)), dim3(256), 0, s,
+                           (const uint8_t*)stage, (const int64_t*)nullptr, stageStride, recLen, (const int64_t*)recOff, (uint8_t*)body, bodyCap);
         HIPCHK(c, hipGetLastError());
     }
+    return PLZ4HIP_OK;
+}
+
+int plz4hip_dev_scatter_records(plz4hip_ctx* c, const void* src, const int64_t* srcOff, const int32_t* len,
+                                const int64_t* dstOff, int n, int maxLen, void* dst, int64_t dstCap, void* stream)
+{
+    if (!c || n < 0 || !src || !srcOff || !len || !dstOff || !dst || maxLen < 0 || dstCap < 0) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_scatter_records: bad argument");
+    if (n == 0) return PLZ4HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_move_records, dim3(n, move_slices(maxLen)), dim3(256), 0, s,
+                       (const uint8_t*)src, srcOff, (int64_t)0, len, dstOff, (uint8_t*)dst, dstCap);
+    HIPCHK(c, hipGetLastError());
     return PLZ4HIP_OK;
 }
 
@@ -383,7 +408,7 @@ int plz4hip_dev_decode_records(plz4hip_ctx* c, const void* body, const int64_t* 
     if (nBlocks == 0) return PLZ4HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream;
     hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
     CodecArgs a{};
     a.src = (const uint8_t*)body; a.recOff = recOff; a.bsz = bsz;

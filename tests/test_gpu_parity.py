@@ -180,8 +180,9 @@ def test_gpu_dev_pipeline(orc, eng):
     d_off = torch.zeros(nblk + 1, dtype=torch.int64, device=dev)
     d_body = torch.empty(data.size + 8 * nblk, dtype=torch.uint8, device=dev)
     s = torch.cuda.current_stream().cuda_stream
-    eng.dev_encode_records(d_src.data_ptr(), data.size, bsz, True, d_stage.data_ptr(), d_len.data_ptr(), d_off.data_ptr(),
-                           d_body.data_ptr(), d_body.numel(), s)
+    eng.dev_encode_records(d_src.data_ptr(), data.size, bsz, True, d_stage.data_ptr(), d_len.data_ptr(), s)
+    eng.dev_compact_records(d_stage.data_ptr(), stride, d_len.data_ptr(), nblk, d_off.data_ptr(),
+                            d_body.data_ptr(), d_body.numel(), s)
     torch.cuda.synchronize()
     total = int(d_off[-1].item())
     assert total == body_want.size
