@@ -18,6 +18,23 @@
 #pragma once
 #include "wave.h"
 
+// Diagnostics build only (-DPLZ4_STATS, scripts/stats_build.sh): per-wave event counts and cycle sums, added to a
+// global array at the end of every block.  Compiled out of the product.
+#if defined(PLZ4_STATS) && !defined(PLZ4_EMU)
+#define STAT(i, v)   (st_[(i)] += (unsigned long long)(v))
+#define STAT_DECL    unsigned long long st_[24] = {0}
+#define STAT_NOW()   ((unsigned long long)__builtin_readcyclecounter())
+#define STAT_FLUSH() do { if (LANE == 0) for (int i_ = 0; i_ < 24; ++i_) atomicAdd(&plz4_stats[i_], st_[i_]); } while (0)
+extern __device__ unsigned long long plz4_stats[24];
+#else
+#define STAT(i, v)   do {} while (0)
+#define STAT_DECL    do {} while (0)
+#define STAT_NOW()   0ull
+#define STAT_FLUSH() do {} while (0)
+#endif
+enum { S_GRID = 0, S_GENERIC, S_MISORDER, S_SEQ_GRID, S_SEQ_GEN, S_TWINSTOP, S_SAT, S_LONGBACK, S_MEMLIT, S_WALKITER,
+       S_CYC_TOTAL, S_CYC_LOAD, S_CYC_WALK, S_CYC_FIX, S_CYC_GEN, S_CYC_SAT, S_CYC_MEMLIT, S_BLOCKS, S_LANES_EXEC };
+
 namespace plz4 {
 
 enum : int {
@@ -170,8 +187,78 @@ DEV int emit_len_ext(uint8_t* dst, int op, int rest)
     return op + nff + 1;
 }
 
+// ---- grid mode helpers -----------------------------------------------------------------------------------
+// 24 bytes around a position x: [x-4, x+20).  back = the 4 bytes before x (as a little-endian u32, byte 3 is
+// x-1), seq = [x, x+8), f1 = [x+8, x+16), f2 = [x+16, x+20).
+struct Win24 { uint32_t back; uint64_t seq; uint64_t f1; uint32_t f2; };
+
+DEV Win24 load_win24(const uint8_t* src, int x)
+{
+    Win24 w;
+    if (x >= 4) {
+        const v16u_t a = *(const v16u_t*)(src + x - 4);           // [x-4, x+12)
+        const uint64_t b = ld64u(src + x + 12);                     // [x+12, x+20)
+        w.back = a.w[0];
+        w.seq  = (uint64_t)a.w[1] | ((uint64_t)a.w[2] << 32);
+        w.f1   = (uint64_t)a.w[3] | (b << 32);
+        w.f2   = (uint32_t)(b >> 32);
+    } else {                                                        // candidates in the first 4 bytes of the block
+        uint32_t bk = 0;
+        for (int i = 0; i < x; ++i) bk |= (uint32_t)src[x - 1 - i] << (8 * (3 - i));
+        w.back = bk;
+        w.seq = ld64u(src + x); w.f1 = ld64u(src + x + 8); w.f2 = ld32u(src + x + 16);
+    }
+    return w;
+}
+
+// equal bytes of [x+4, x+20) in two windows: 0..16
+DEV int win_fwd(const Win24& p, const Win24& c)
+{
+    const uint32_t x0 = (uint32_t)(p.seq >> 32) ^ (uint32_t)(c.seq >> 32);
+    if (x0) return __builtin_ctz(x0) >> 3;
+    const uint64_t x1 = p.f1 ^ c.f1;
+    if (x1) return 4 + (ctz64(x1) >> 3);
+    const uint32_t x2 = p.f2 ^ c.f2;
+    if (x2) return 12 + (__builtin_ctz(x2) >> 3);
+    return 16;
+}
+// equal bytes going backwards from x-1: 0..4
+DEV int win_bck(const Win24& p, const Win24& c)
+{
+    const uint32_t y = p.back ^ c.back;
+    return y ? (__builtin_clz(y) >> 3) : 4;
+}
+
+#if defined(PLZ4_EMU)
+static inline uint32_t lds_max_rtn(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
+static inline void     lds_min(uint32_t* p, uint32_t v)     { if (v < *p) *p = v; }
+static inline void     lds_max(uint32_t* p, uint32_t v)     { if (v > *p) *p = v; }
+#else
+__device__ __forceinline__ uint32_t lds_max_rtn(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
+__device__ __forceinline__ void     lds_min(uint32_t* p, uint32_t v)     { atomicMin(p, v); }
+__device__ __forceinline__ void     lds_max(uint32_t* p, uint32_t v)     { atomicMax(p, v); }
+#endif
+
+DEV uint64_t lane_range(int lo, int hi)          // bits lo..hi inclusive, 0 <= lo, hi <= 63; empty if hi < lo
+{
+    if (hi < lo) return 0;
+    const uint64_t upto = (hi >= 63) ? ~0ull : ((1ull << (hi + 1)) - 1);
+    return upto & (~0ull << lo);
+}
+
 // Returns the compressed size, or 0 when liblz4 would return 0 (`limited` and the output does not fit its
 // conservative checks).  `tab` = 16 KiB of LDS owned by this wave.  noDict (independent blocks, no dictionary).
+//
+// Two kinds of batch, same parser state between them:
+//   GRID  (byU32 only, away from both ends of the block, probe stride still 1): the 64 lanes are the 64
+//         consecutive positions of an aligned window.  One LDS atomic-max per lane commits the position and
+//         returns the candidate; one memory round trip brings every lane 24 bytes around its position and
+//         around its candidate, so hit / forward length (<=16 beyond the 4) / backward length (<=4) are known
+//         for all 64 positions at once.  A scalar walk then plays the sequential parser over the window --
+//         usually several sequences per batch -- and the table is patched (atomic-min for positions the
+//         parser skipped, atomic-max for the ones it executed) to exactly the sequential result.
+//   GENERIC (everything else: byU16, block head/tail, stride > 1): one lane per probe of the search loop,
+//         closed-form probe positions, plain store + read-back collision detection, one sequence per batch.
 template <bool U16>
 DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst,
                              const int cap, const bool limited, void* tab)
@@ -183,15 +270,163 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
     const int lastProbe  = n - kMfLimit + 1;      // mflimitPlusOne (lz4.c:963)
     const int matchLimit = n - kLastLiterals;     // lz4.c:964
     int anchor = 0, op = 0;
+    STAT_DECL;
+    const unsigned long long tBlock0 = STAT_NOW();
+    (void)tBlock0;
 
     if (n >= kMinLength) {
-        // Parser state between batches.  A batch is: [insert-only lane][re-test lane][search lanes...]
-        int  insPos  = 0;  bool hasIns = true;     // "First Byte": table[hash(0)] = 0 (lz4.c:1005-1010)
-        int  rePos   = 0;  bool hasRe  = false;    // immediate re-test at ip after a match (lz4.c:1255-1294)
+        // Parser state between batches.
+        int  insPos  = 0;  bool hasIns = true;     // pending table insert ("First Byte" lz4.c:1005-1010; ip-2 lz4.c:1236-1242)
+        int  rePos   = 0;  bool hasRe  = false;    // pending immediate re-test at ip after a match (lz4.c:1255-1294)
         int  sBase   = 1;  int  sIter  = 0;        // search started at sBase; next un-probed probe number
-        int  width   = 16;                         // lanes offered to this batch (16 first, 64 when a search drags on)
+        int  width   = 16;                         // generic batches: 16 lanes first, 64 when a search drags on
 
         for (;;) {
+            // ================================================================ GRID batch
+            if (!U16 && sIter <= 64) {
+                const int probeStart = hasRe ? rePos : sBase + sIter;
+                const int firstPos   = hasIns ? insPos : probeStart;
+                const int base       = firstPos & ~63;
+                if (base >= 64 && base + 96 <= n) {
+                    uint32_t* T = (uint32_t*)tab;
+                    STAT(S_GRID, 1);
+                    const unsigned long long tg0 = STAT_NOW(); (void)tg0;
+                    LV(int, act); LV(uint32_t, h); LV(uint32_t, r); LV(uint32_t, lit8);
+                    LV(int, hit); LV(int, fwd); LV(int, bck);
+                    LANES({
+                        const int q = base + LANE;
+                        const int isIns = hasIns && q == insPos;
+                        act[I_] = isIns || q >= probeStart;
+                        hit[I_] = 0; fwd[I_] = 0; bck[I_] = 0; r[I_] = 0; h[I_] = 0;
+                        const Win24 P = load_win24(src, q);         // every lane: its byte may be a pending literal
+                        lit8[I_] = (uint32_t)(P.seq & 0xFF);
+                        if (act[I_]) {
+                            h[I_] = seq_hash<false>(P.seq);
+                            r[I_] = lds_max_rtn(&T[h[I_]], (uint32_t)q);
+                            if (!isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q) {
+                                const Win24 Cw = load_win24(src, (int)r[I_]);
+                                if ((uint32_t)Cw.seq == (uint32_t)P.seq) {
+                                    hit[I_] = 1;
+                                    fwd[I_] = win_fwd(P, Cw);
+                                    bck[I_] = min_(win_bck(P, Cw), (int)r[I_]);
+                                }
+                            }
+                        }
+                    })
+                    LDS_FENCE();
+                    // LDS atomics on one slot are expected to resolve in ascending lane order (then r is the
+                    // nearest earlier twin or the pre-batch value).  Any other order shows up as r >= q somewhere.
+                    const uint64_t misorder = BALLOT(act[I_] && r[I_] >= (uint32_t)(base + LANE));
+                    if (misorder) {
+                        STAT(S_MISORDER, 1);
+                        LANES({ if (act[I_]) lds_min(&T[h[I_]], r[I_]); })     // min over a slot's group == its pre-batch value
+                        LDS_FENCE();
+                        goto generic_batch;
+                    }
+                    {
+                        const uint64_t hits   = BALLOT(hit[I_]);
+                        const uint64_t twins  = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);   // has an earlier twin in this batch
+                        const uint64_t actM   = BALLOT(act[I_]);
+                        const unsigned long long tg1 = STAT_NOW(); (void)tg1;
+                        STAT(S_CYC_LOAD, tg1 - tg0);
+                        uint64_t E = 0;                                       // lanes the sequential parser really executes
+                        if (hasIns) { E |= 1ull << (insPos - base); hasIns = false; }
+                        int  cur = probeStart - base;                         // next probe lane (may be >= 64: none here)
+                        bool curIsRe = hasRe;
+                        bool finished = false;
+                        if (cur < 64) hasRe = false;                          // consumed by the walk below
+
+                        while (cur < 64) {
+                            STAT(S_WALKITER, 1);
+                            const uint64_t hm = hits & (~0ull << cur);
+                            const int w = hm ? ctz64(hm) : 64;
+                            int lim = 63;                                     // probe number <= 65 keeps the stride at 1
+                            { const int x = sBase + 65 - base; if (x < lim) lim = x; }
+                            int last = min_(w, lim);
+                            // a lane with an earlier twin is only right if that twin was itself executed
+                            const int curL = cur; const uint64_t EE = E;
+                            const uint64_t bad = twins & lane_range(cur, max_(last, cur) > 63 ? 63 : max_(last, cur)) &
+                                BALLOT(((int)r[I_] - base) < curL && !((EE >> (((int)r[I_] - base) & 63)) & 1));
+                            bool stopForTwin = false;
+                            if (bad) { const int b = ctz64(bad); if (b <= last) { last = b - 1; stopForTwin = true; STAT(S_TWINSTOP, 1); } }
+
+                            if (w <= last) {
+                                // ---- match at lane w
+                                E |= lane_range(cur, w);
+                                STAT(S_SEQ_GRID, 1);
+                                const bool isRe = curIsRe && (w == cur);
+                                const int p0 = base + w, c0 = (int)RL(r, w);
+                                int p = p0, c = c0;
+                                if (!isRe) {                                   // catch-up (lz4.c:1105-1109)
+                                    const int maxBack = min_(p - anchor, c);
+                                    int back = min_((int)RL(bck, w), maxBack);
+                                    if (back == 4 && maxBack > 4) { STAT(S_LONGBACK, 1); back += wave_common_back(src, p - 4, c - 4, maxBack - 4); }
+                                    p -= back; c -= back;
+                                }
+                                const int lit = p - anchor;
+                                const int tokPos = op++;
+                                if (limited && !isRe && (int64_t)op + lit + (2 + 1 + kLastLiterals) + lit / 255 > cap) return 0;
+                                if (lit >= 15) op = emit_len_ext(dst, op, lit - 15);
+                                if (lit > 0) {
+                                    if (anchor < base) { STAT(S_MEMLIT, 1); const unsigned long long tm0 = STAT_NOW(); (void)tm0;
+                                        wave_copy(dst + op, src + anchor, min_(lit, base - anchor)); STAT(S_CYC_MEMLIT, STAT_NOW() - tm0); }
+                                    const int opl = op, an = anchor, pe = p;
+                                    LANES({ const int q = base + LANE; if (q >= an && q < pe) dst[opl + (q - an)] = (uint8_t)lit8[I_]; })
+                                }
+                                op += lit;
+                                LANES({ if (LANE == 0) st16u(dst + op, (uint16_t)(p - c)); })
+                                op += 2;
+                                int mc = (int)RL(fwd, w);
+                                if (mc == 16) { STAT(S_SAT, 1); const unsigned long long ts0 = STAT_NOW(); (void)ts0;
+                                    mc += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); STAT(S_CYC_SAT, STAT_NOW() - ts0); }
+                                const int e = p0 + kMinMatch + mc;
+                                mc += p0 - p;                                  // the match starts `back` bytes earlier
+                                if (limited && (int64_t)op + (1 + kLastLiterals) + (mc + 240) / 255 > cap) return 0;
+                                LANES({ if (LANE == 0) dst[tokPos] = (uint8_t)((min_(lit, 15) << 4) | min_(mc, 15)); })
+                                if (mc >= 15) op = emit_len_ext(dst, op, mc - 15);
+
+                                anchor = e;
+                                if (e >= lastProbe) { finished = true; break; }                 // lz4.c:1233
+                                if (e - 2 < base + 64) E |= 1ull << (e - 2 - base);             // lz4.c:1236-1242
+                                else { hasIns = true; insPos = e - 2; }
+                                sBase = e + 1; sIter = 0;
+                                if (e < base + 64) { cur = e - base; curIsRe = true; continue; }
+                                hasRe = true; rePos = e;
+                                break;
+                            }
+                            // ---- no match up to `last`: those probes are misses
+                            if (last >= cur) {
+                                E |= lane_range(cur, last);
+                                if (curIsRe) { curIsRe = false; }             // the re-test missed; search runs from sBase (= its pos + 1)
+                            }
+                            {
+                                const int nextPos = base + last + 1;
+                                if (curIsRe) { hasRe = true; rePos = nextPos; }   // nothing executed yet (twin stop right at the re-test)
+                                else sIter = nextPos - sBase;
+                            }
+                            (void)stopForTwin;
+                            break;
+                        }
+                        if (finished) break;
+                        const unsigned long long tg2 = STAT_NOW(); (void)tg2;
+                        STAT(S_CYC_WALK, tg2 - tg1);
+                        STAT(S_LANES_EXEC, __builtin_popcountll(E));
+                        // ---- patch the table to the sequential result
+                        LANES({ if (act[I_] && !((E >> LANE) & 1)) lds_min(&T[h[I_]], r[I_]); })
+                        if (twins) { LDS_FENCE(); LANES({ if ((E >> LANE) & 1) lds_max(&T[h[I_]], (uint32_t)(base + LANE)); }) }
+                        LDS_FENCE();
+                        (void)actM;
+                        STAT(S_CYC_FIX, STAT_NOW() - tg2);
+                        width = 64;
+                        continue;
+                    }
+                }
+            }
+generic_batch:
+            // ================================================================ GENERIC batch
+            {
+            STAT(S_GENERIC, 1);
+            const unsigned long long tq0 = STAT_NOW(); (void)tq0;
             const int pre = (hasIns ? 1 : 0) + (hasRe ? 1 : 0);
             LV(int, q); LV(uint32_t, h); LV(uint32_t, old); LV(uint32_t, rb); LV(uint32_t, lo4);
             LV(int, ok);        // lane has a probe to make (not past the end-of-block stop, within width)
@@ -251,6 +486,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                 if (hasIns && used > 0) { hasIns = false; used--; }
                 if (hasRe  && used > 0) { hasRe = false; used--; }
                 sIter += used;
+                STAT(S_CYC_GEN, STAT_NOW() - tq0);
                 if (keep == nproc && endInBatch && !hasIns && !hasRe) break;      // -> last literals (lz4.c:1055)
                 width = 64;
                 continue;
@@ -292,6 +528,9 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
             hasIns = true; insPos = ip - 2;
             hasRe = true;  rePos = ip;
             sBase = ip + 1; sIter = 0; width = 16;
+            STAT(S_SEQ_GEN, 1);
+            STAT(S_CYC_GEN, STAT_NOW() - tq0);
+            }
         }
     }
 
@@ -309,6 +548,9 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
         wave_copy(dst + op, src + anchor, last);
         op += last;
     }
+    STAT(S_CYC_TOTAL, STAT_NOW() - tBlock0);
+    STAT(S_BLOCKS, 1);
+    STAT_FLUSH();
     return op;
 }
 

@@ -13,6 +13,9 @@
 #include <cstring>
 
 #include "../../include/plz4hip.h"
+#if defined(PLZ4_STATS)
+__device__ unsigned long long plz4_stats[24];
+#endif
 #include "lz4_device.inl"
 
 namespace {
@@ -247,6 +250,18 @@ int grid_for(int nBlocks, int resident) { return nBlocks < resident ? nBlocks : 
 extern "C" {
 
 int plz4hip_abi_version(void) { return PLZ4HIP_ABI_VERSION; }
+
+#if defined(PLZ4_STATS)
+// diagnostics build only: read-and-reset the device counters
+int plz4hip_debug_stats(unsigned long long* out24)
+{
+    unsigned long long zero[24] = {0};
+    if (hipDeviceSynchronize() != hipSuccess) return PLZ4HIP_E_DEVICE;
+    if (hipMemcpyFromSymbol(out24, HIP_SYMBOL(plz4_stats), sizeof zero) != hipSuccess) return PLZ4HIP_E_DEVICE;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(plz4_stats), zero, sizeof zero) != hipSuccess) return PLZ4HIP_E_DEVICE;
+    return PLZ4HIP_OK;
+}
+#endif
 
 int plz4hip_device_count(void)
 {

@@ -51,3 +51,22 @@ def block_cases_64k():
         cases.append(("S%d" % n, structured(n, seed=n)))
         cases.append(("Z%d" % n, np.zeros(n, dtype=np.uint8)))
     return cases
+
+
+def twin_cases():
+    """Inputs that force same-slot hash collisions inside one 64-position batch (the 'twin' paths of the grid
+    encoder): short periods, tiny alphabets, and text with periodic islands."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    cases = []
+    for period in (1, 2, 3, 5, 7, 13, 31, 63, 64, 65, 127):
+        unit = rng.integers(0, 256, size=period, dtype=np.uint8)
+        cases.append(("P%d" % period, np.tile(unit, 200000 // period + 1)[:200000]))
+    for alpha in (2, 3, 4, 8):
+        cases.append(("A%d" % alpha, rng.integers(0, alpha, size=150000, dtype=np.uint8)))
+    t = synth.text(300000, seed=5).copy()
+    for k in range(40):
+        off = int(rng.integers(1000, 290000)); per = int(rng.integers(1, 40)); ln = int(rng.integers(20, 3000))
+        unit = t[off:off + per].copy()
+        t[off:off + ln] = np.tile(unit, ln // per + 1)[:ln]
+    cases.append(("Tislands", t))
+    return cases

@@ -49,6 +49,12 @@ def test_emu_encode_structured(orc, emu_o):
         _enc(orc, emu_o, src, orc.bound(n))
 
 
+def test_emu_encode_twins(orc, emu_o):
+    for name, src in corpus.twin_cases():
+        _enc(orc, emu_o, src, src.size)
+        _enc(orc, emu_o, src, orc.bound(src.size))
+
+
 def test_emu_encode_limited_threshold(orc, emu):
     src = corpus.structured(5000, 2)
     full, _ = orc.compress_fast(src, orc.bound(src.size))

@@ -51,6 +51,13 @@ def test_gpu_encode_structured(orc, eng):
     _check_encode(orc, eng, srcs, caps)
 
 
+def test_gpu_encode_twins(orc, eng):
+    srcs, caps = [], []
+    for name, src in corpus.twin_cases():
+        srcs += [src, src]; caps += [src.size, orc.bound(src.size)]
+    _check_encode(orc, eng, srcs, caps)
+
+
 def test_gpu_encode_limited_threshold(orc, eng):
     src = corpus.structured(5000, 2)
     full, _ = orc.compress_fast(src, orc.bound(src.size))
