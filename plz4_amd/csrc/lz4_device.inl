@@ -259,12 +259,25 @@ DEV uint64_t lane_range(int lo, int hi)          // bits lo..hi inclusive, 0 <= 
 //         parser skipped, atomic-max for the ones it executed) to exactly the sequential result.
 //   GENERIC (everything else: byU16, block head/tail, stride > 1): one lane per probe of the search loop,
 //         closed-form probe positions, plain store + read-back collision detection, one sequence per batch.
+//
+// Table entries (byU32): liblz4 stores the position.  Positions of a block of <= 4 MiB need 22 bits, so the
+// private LDS copy keeps (position << 10) | tag, tag = 10 hash bits of the 4 bytes at that position.  Ordering by
+// entry == ordering by position, and a candidate whose tag differs cannot pass the 4-byte test, so its bytes are
+// never fetched: that removes most of the random memory reads.  An empty liblz4 slot is position 0, therefore
+// the table is initialised with position 0's entry, not with zero.  Larger blocks (raw block API) run untagged.
+DEV uint32_t seq_tag(uint32_t seq4) { return (seq4 * 2246822519u) >> 22; }
+
 template <bool U16>
 DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst,
                              const int cap, const bool limited, void* tab)
 {
-    // fresh zeroed table per block (LZ4_initStream, lz4.c:1384)
-    LANES({ uint32_t* t = (uint32_t*)tab; for (int i = LANE; i < kHashBytes / 4; i += 64) t[i] = 0; })
+    const int      sh      = (!U16 && n <= (1 << 22)) ? 10 : 0;
+    const uint32_t tagMask = (1u << sh) - 1u;
+    // fresh table per block (LZ4_initStream, lz4.c:1384): every slot = "position 0"
+    {
+        const uint32_t e0 = (sh && n >= 4) ? (seq_tag(UNI(ld32u(src))) & tagMask) : 0u;
+        LANES({ uint32_t* t = (uint32_t*)tab; for (int i = LANE; i < kHashBytes / 4; i += 64) t[i] = e0; })
+    }
     LDS_FENCE();
 
     const int lastProbe  = n - kMfLimit + 1;      // mflimitPlusOne (lz4.c:963)
@@ -280,6 +293,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
         int  rePos   = 0;  bool hasRe  = false;    // pending immediate re-test at ip after a match (lz4.c:1255-1294)
         int  sBase   = 1;  int  sIter  = 0;        // search started at sBase; next un-probed probe number
         int  width   = 16;                         // generic batches: 16 lanes first, 64 when a search drags on
+        LV(Win24, Pn); int prefBase = -1;          // next window's bytes, requested one batch ahead
+        LANES({ Pn[I_].back = 0; Pn[I_].seq = 0; Pn[I_].f1 = 0; Pn[I_].f2 = 0; })
 
         for (;;) {
             // ================================================================ GRID batch
@@ -290,20 +305,24 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                 if (base >= 64 && base + 96 <= n) {
                     uint32_t* T = (uint32_t*)tab;
                     STAT(S_GRID, 1);
-                    const unsigned long long tg0 = STAT_NOW(); (void)tg0;
                     LV(int, act); LV(uint32_t, h); LV(uint32_t, r); LV(uint32_t, lit8);
-                    LV(int, hit); LV(int, fwd); LV(int, bck);
+                    LV(uint32_t, ent); LV(uint32_t, rent);           // my table entry / the entry I displaced
+                    LV(int, hit); LV(int, fwd); LV(int, bck); LV(int, eLane);
+                    // ---- 1. every lane: its window, the table exchange, its candidate's window
                     LANES({
                         const int q = base + LANE;
                         const int isIns = hasIns && q == insPos;
                         act[I_] = isIns || q >= probeStart;
-                        hit[I_] = 0; fwd[I_] = 0; bck[I_] = 0; r[I_] = 0; h[I_] = 0;
-                        const Win24 P = load_win24(src, q);         // every lane: its byte may be a pending literal
+                        hit[I_] = 0; fwd[I_] = 0; bck[I_] = 0; r[I_] = 0; h[I_] = 0; ent[I_] = 0; rent[I_] = 0;
+                        const Win24 P = (base == prefBase) ? Pn[I_] : load_win24(src, q);   // every lane: its byte may be a pending literal
                         lit8[I_] = (uint32_t)(P.seq & 0xFF);
                         if (act[I_]) {
                             h[I_] = seq_hash<false>(P.seq);
-                            r[I_] = lds_max_rtn(&T[h[I_]], (uint32_t)q);
-                            if (!isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q) {
+                            const uint32_t tg = seq_tag((uint32_t)P.seq) & tagMask;
+                            ent[I_]  = ((uint32_t)q << sh) | tg;
+                            rent[I_] = lds_max_rtn(&T[h[I_]], ent[I_]);
+                            r[I_]    = rent[I_] >> sh;
+                            if (!isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q && (rent[I_] & tagMask) == tg) {
                                 const Win24 Cw = load_win24(src, (int)r[I_]);
                                 if ((uint32_t)Cw.seq == (uint32_t)P.seq) {
                                     hit[I_] = 1;
@@ -312,111 +331,181 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                 }
                             }
                         }
+                        eLane[I_] = LANE + kMinMatch + fwd[I_];     // lane index just past a match that starts here
+                        if (base + 160 <= n) Pn[I_] = load_win24(src, q + 64);   // request the next window now, use it next batch
                     })
+                    prefBase = (base + 160 <= n) ? base + 64 : -1;
                     LDS_FENCE();
                     // LDS atomics on one slot are expected to resolve in ascending lane order (then r is the
                     // nearest earlier twin or the pre-batch value).  Any other order shows up as r >= q somewhere.
                     const uint64_t misorder = BALLOT(act[I_] && r[I_] >= (uint32_t)(base + LANE));
                     if (misorder) {
                         STAT(S_MISORDER, 1);
-                        LANES({ if (act[I_]) lds_min(&T[h[I_]], r[I_]); })     // min over a slot's group == its pre-batch value
+                        LANES({ if (act[I_]) lds_min(&T[h[I_]], rent[I_]); })  // min over a slot's group == its pre-batch value
                         LDS_FENCE();
                         goto generic_batch;
                     }
                     {
-                        const uint64_t hits   = BALLOT(hit[I_]);
-                        const uint64_t twins  = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);   // has an earlier twin in this batch
-                        const uint64_t actM   = BALLOT(act[I_]);
-                        const unsigned long long tg1 = STAT_NOW(); (void)tg1;
-                        STAT(S_CYC_LOAD, tg1 - tg0);
-                        uint64_t E = 0;                                       // lanes the sequential parser really executes
-                        if (hasIns) { E |= 1ull << (insPos - base); hasIns = false; }
-                        int  cur = probeStart - base;                         // next probe lane (may be >= 64: none here)
-                        bool curIsRe = hasRe;
-                        bool finished = false;
-                        if (cur < 64) hasRe = false;                          // consumed by the walk below
+                        const uint64_t hits  = BALLOT(hit[I_]);
+                        const uint64_t twins = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);    // earlier twin inside this batch
+                        uint64_t specialLeft = BALLOT(hit[I_] && (fwd[I_] == 16 || (bck[I_] == 4 && r[I_] > 4)));
+                        const int  cur0 = probeStart - base;                  // first probe lane (>= 64: none in this batch)
+                        const bool re0  = hasRe;
+                        const uint64_t insBit0 = hasIns ? (1ull << (insPos - base)) : 0;
+                        int lim0 = sBase + 65 - base; if (lim0 > 63) lim0 = 63;   // probe number <= 65 keeps the stride at 1
 
-                        while (cur < 64) {
-                            STAT(S_WALKITER, 1);
-                            const uint64_t hm = hits & (~0ull << cur);
-                            const int w = hm ? ctz64(hm) : 64;
-                            int lim = 63;                                     // probe number <= 65 keeps the stride at 1
-                            { const int x = sBase + 65 - base; if (x < lim) lim = x; }
-                            int last = min_(w, lim);
-                            // a lane with an earlier twin is only right if that twin was itself executed
-                            const int curL = cur; const uint64_t EE = E;
-                            const uint64_t bad = twins & lane_range(cur, max_(last, cur) > 63 ? 63 : max_(last, cur)) &
-                                BALLOT(((int)r[I_] - base) < curL && !((EE >> (((int)r[I_] - base) & 63)) & 1));
-                            bool stopForTwin = false;
-                            if (bad) { const int b = ctz64(bad); if (b <= last) { last = b - 1; stopForTwin = true; STAT(S_TWINSTOP, 1); } }
-
-                            if (w <= last) {
-                                // ---- match at lane w
-                                E |= lane_range(cur, w);
-                                STAT(S_SEQ_GRID, 1);
-                                const bool isRe = curIsRe && (w == cur);
-                                const int p0 = base + w, c0 = (int)RL(r, w);
-                                int p = p0, c = c0;
-                                if (!isRe) {                                   // catch-up (lz4.c:1105-1109)
-                                    const int maxBack = min_(p - anchor, c);
-                                    int back = min_((int)RL(bck, w), maxBack);
-                                    if (back == 4 && maxBack > 4) { STAT(S_LONGBACK, 1); back += wave_common_back(src, p - 4, c - 4, maxBack - 4); }
-                                    p -= back; c -= back;
+                        // ---- 2. scalar hop over the recorded matches only; everything else is derived per lane
+                        int      S = 64;           // first lane NOT executed as a probe (a wrong twin lowers it and the hop is redone)
+                        uint64_t mm = 0;           // executed match lanes
+                        int      eL = 0;           // end lane of the last executed match
+                        uint64_t E = 0;            // executed lanes (probes + inserts)
+                        int      Send = 0;
+                        bool     finished = false;
+                        LV(int, stA); LV(int, hasPm);
+                        for (;;) {
+                            const uint64_t hitsS = (S >= 64) ? hits : (hits & ((1ull << S) - 1));
+                            LV(int, nextHit);
+                            LANES({
+                                const uint64_t ah = (eLane[I_] < 64) ? (hitsS >> eLane[I_]) : 0;
+                                nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
+                            })
+                            mm = 0; eL = 0; finished = false;
+                            int w = 64;
+                            if (cur0 < S) { const uint64_t hm = hitsS & (~0ull << cur0); if (hm) w = ctz64(hm); }
+                            if (w < S && w <= lim0) {
+                                int aCur = anchor;
+                                for (;;) {
+                                    STAT(S_WALKITER, 1);
+                                    if ((specialLeft >> w) & 1) {
+                                        // longer than the speculative window (forwards and/or backwards): finish it now
+                                        const int p0 = base + w, c0 = (int)RL(r, w);
+                                        int mc0 = (int)RL(fwd, w);
+                                        if (mc0 == 16) { STAT(S_SAT, 1); mc0 += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); WL(fwd, w, mc0); }
+                                        const bool isRe = mm ? (w == eL) : (re0 && w == cur0);
+                                        if (!isRe && (int)RL(bck, w) == 4) {
+                                            const int maxBack = min_(p0 - aCur, c0);
+                                            if (maxBack > 4) { STAT(S_LONGBACK, 1); WL(bck, w, 4 + wave_common_back(src, p0 - 4, c0 - 4, maxBack - 4)); }
+                                        }
+                                        specialLeft &= ~(1ull << w);
+                                        eL = w + kMinMatch + mc0;
+                                        WL(eLane, w, eL);
+                                        mm |= 1ull << w;
+                                        aCur = base + eL;
+                                        if (aCur >= lastProbe) { finished = true; break; }        // lz4.c:1233
+                                        if (eL >= S) break;
+                                        const uint64_t hm = hitsS & (~0ull << eL);
+                                        w = hm ? ctz64(hm) : 64;
+                                    } else {
+                                        mm |= 1ull << w;
+                                        eL = RL(eLane, w);
+                                        aCur = base + eL;
+                                        if (eL >= S) break;
+                                        w = RL(nextHit, w);
+                                    }
+                                    if (w >= S) break;
                                 }
-                                const int lit = p - anchor;
-                                const int tokPos = op++;
-                                if (limited && !isRe && (int64_t)op + lit + (2 + 1 + kLastLiterals) + lit / 255 > cap) return 0;
-                                if (lit >= 15) op = emit_len_ext(dst, op, lit - 15);
-                                if (lit > 0) {
-                                    if (anchor < base) { STAT(S_MEMLIT, 1); const unsigned long long tm0 = STAT_NOW(); (void)tm0;
-                                        wave_copy(dst + op, src + anchor, min_(lit, base - anchor)); STAT(S_CYC_MEMLIT, STAT_NOW() - tm0); }
-                                    const int opl = op, an = anchor, pe = p;
-                                    LANES({ const int q = base + LANE; if (q >= an && q < pe) dst[opl + (q - an)] = (uint8_t)lit8[I_]; })
-                                }
-                                op += lit;
-                                LANES({ if (LANE == 0) st16u(dst + op, (uint16_t)(p - c)); })
-                                op += 2;
-                                int mc = (int)RL(fwd, w);
-                                if (mc == 16) { STAT(S_SAT, 1); const unsigned long long ts0 = STAT_NOW(); (void)ts0;
-                                    mc += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); STAT(S_CYC_SAT, STAT_NOW() - ts0); }
-                                const int e = p0 + kMinMatch + mc;
-                                mc += p0 - p;                                  // the match starts `back` bytes earlier
-                                if (limited && (int64_t)op + (1 + kLastLiterals) + (mc + 240) / 255 > cap) return 0;
-                                LANES({ if (LANE == 0) dst[tokPos] = (uint8_t)((min_(lit, 15) << 4) | min_(mc, 15)); })
-                                if (mc >= 15) op = emit_len_ext(dst, op, mc - 15);
-
-                                anchor = e;
-                                if (e >= lastProbe) { finished = true; break; }                 // lz4.c:1233
-                                if (e - 2 < base + 64) E |= 1ull << (e - 2 - base);             // lz4.c:1236-1242
-                                else { hasIns = true; insPos = e - 2; }
-                                sBase = e + 1; sIter = 0;
-                                if (e < base + 64) { cur = e - base; curIsRe = true; continue; }
-                                hasRe = true; rePos = e;
-                                break;
                             }
-                            // ---- no match up to `last`: those probes are misses
-                            if (last >= cur) {
-                                E |= lane_range(cur, last);
-                                if (curIsRe) { curIsRe = false; }             // the re-test missed; search runs from sBase (= its pos + 1)
+                            // ---- 3. which lanes did the sequential parser execute
+                            Send = mm ? S : min_(S, lim0 + 1);
+                            const uint64_t mmL = mm; const int SendL = Send;
+                            LANES({
+                                const uint64_t below = mmL & ((1ull << LANE) - 1);        // match lanes strictly below me
+                                const int pm = below ? 63 - __builtin_clzll(below) : -1;
+                                const int ePrev = SHFL(eLane, pm < 0 ? LANE : pm);
+                                hasPm[I_] = pm >= 0;
+                                stA[I_]   = pm >= 0 ? ePrev : cur0;                        // where probing resumed before me
+                            })
+                            const uint64_t probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
+                            E = probes | insBit0 | BALLOT(hasPm[I_] && stA[I_] == LANE + 2);   // + the ip-2 inserts (lz4.c:1236-1242)
+                            if (twins & probes) {
+                                // a probe whose candidate is an earlier lane of this batch is only right if that lane was executed
+                                const uint64_t EL = E;
+                                const uint64_t bad = twins & probes & BALLOT(!((EL >> (((int)r[I_] - base) & 63)) & 1));
+                                if (bad) { STAT(S_TWINSTOP, 1); S = ctz64(bad); continue; }
                             }
-                            {
-                                const int nextPos = base + last + 1;
-                                if (curIsRe) { hasRe = true; rePos = nextPos; }   // nothing executed yet (twin stop right at the re-test)
-                                else sIter = nextPos - sBase;
-                            }
-                            (void)stopForTwin;
                             break;
                         }
-                        if (finished) break;
-                        const unsigned long long tg2 = STAT_NOW(); (void)tg2;
-                        STAT(S_CYC_WALK, tg2 - tg1);
+                        STAT(S_SEQ_GRID, __builtin_popcountll(mm));
                         STAT(S_LANES_EXEC, __builtin_popcountll(E));
-                        // ---- patch the table to the sequential result
-                        LANES({ if (act[I_] && !((E >> LANE) & 1)) lds_min(&T[h[I_]], r[I_]); })
-                        if (twins) { LDS_FENCE(); LANES({ if ((E >> LANE) & 1) lds_max(&T[h[I_]], (uint32_t)(base + LANE)); }) }
+
+                        // ---- 4. emit every recorded sequence at once
+                        if (mm) {
+                            LV(int, anc); LV(int, lit); LV(int, mcT); LV(int, extL); LV(int, extM); LV(int, size); LV(int, tok);
+                            LV(int, pS); LV(int, litDst);
+                            const int anchor0 = anchor;
+                            LANES({
+                                const int q = base + LANE;
+                                anc[I_] = hasPm[I_] ? base + stA[I_] : anchor0;
+                                const int bk = min_(bck[I_], min_(q - anc[I_], (int)r[I_]));     // lz4.c:1105-1109 (0 for a re-test)
+                                pS[I_]   = q - bk;
+                                lit[I_]  = q - bk - anc[I_];
+                                mcT[I_]  = fwd[I_] + bk;
+                                extL[I_] = lit[I_] >= 15 ? (lit[I_] - 15) / 255 + 1 : 0;
+                                extM[I_] = mcT[I_] >= 15 ? (mcT[I_] - 15) / 255 + 1 : 0;
+                                size[I_] = 1 + extL[I_] + lit[I_] + 2 + extM[I_];
+                                tok[I_]  = 0;
+                            })
+                            for (uint64_t m = mm; m; m &= m - 1) {            // output cursor per sequence, in order
+                                const int w = ctz64(m);
+                                WL(tok, w, op);
+                                op += RL(size, w);
+                            }
+                            const uint64_t mmL = mm;
+                            if (limited) {                                     // lz4.c:1114-1117 and :1187-1210, per sequence
+                                const uint64_t over = BALLOT(((mmL >> LANE) & 1) &&
+                                    ((!(hasPm[I_] ? (LANE == stA[I_]) : (re0 && LANE == cur0)) &&
+                                      (int64_t)tok[I_] + 1 + lit[I_] + (2 + 1 + kLastLiterals) + lit[I_] / 255 > cap) ||
+                                     ((int64_t)tok[I_] + 1 + extL[I_] + lit[I_] + 2 + (1 + kLastLiterals) + (mcT[I_] + 240) / 255 > cap)));
+                                if (over) return 0;
+                            }
+                            LANES({
+                                litDst[I_] = tok[I_] + 1 + extL[I_];
+                                if ((mmL >> LANE) & 1) {
+                                    const int t = tok[I_];
+                                    dst[t] = (uint8_t)((min_(lit[I_], 15) << 4) | min_(mcT[I_], 15));
+                                    int o = t + 1;
+                                    if (extL[I_]) { int rest = lit[I_] - 15; for (; rest >= 255; rest -= 255) dst[o++] = 255; dst[o++] = (uint8_t)rest; }
+                                    o += lit[I_];
+                                    st16u(dst + o, (uint16_t)((uint32_t)(base + LANE) - r[I_]));
+                                    o += 2;
+                                    if (extM[I_]) { int rest = mcT[I_] - 15; for (; rest >= 255; rest -= 255) dst[o++] = 255; dst[o++] = (uint8_t)rest; }
+                                }
+                            })
+                            // literals: every lane looks up the next recorded match at or after it
+                            LANES({
+                                const uint64_t ahead = mmL >> LANE;
+                                const int m = ahead ? LANE + ctz64(ahead) : LANE;   // all lanes take part in the exchange
+                                const int a = SHFL(anc, m), pe = SHFL(pS, m), ld = SHFL(litDst, m);
+                                const int q = base + LANE;
+                                if (ahead && q >= a && q < pe) dst[ld + (q - a)] = (uint8_t)lit8[I_];
+                            })
+                            {   // the part of the first run that lies before this window comes from memory
+                                const int w0 = ctz64(mm);
+                                const int a0 = RL(anc, w0);
+                                if (a0 < base) { STAT(S_MEMLIT, 1); wave_copy(dst + RL(litDst, w0), src + a0, min_(RL(lit, w0), base - a0)); }
+                            }
+                            anchor = base + eL;
+                        }
+                        if (finished) break;
+
+                        // ---- 5. parser state after this batch
+                        hasIns = false;
+                        if (cur0 < 64) hasRe = false;
+                        if (mm) {
+                            sBase = base + eL + 1; sIter = 0;
+                            if (eL - 2 >= 64) { hasIns = true; insPos = base + eL - 2; }
+                            if (eL >= Send) { hasRe = true; rePos = base + eL; }       // its re-test is not executed in this batch
+                            else sIter = (base + Send) - sBase;                         // lanes eL..Send-1 missed (eL was the re-test)
+                        } else if (cur0 < 64) {
+                            if (Send > cur0) sIter = (base + Send) - sBase;             // lanes cur0..Send-1 missed
+                            else if (re0) { hasRe = true; rePos = base + cur0; }
+                        }
+
+                        // ---- 6. patch the table to the sequential result
+                        const uint64_t EL2 = E;
+                        LANES({ if (act[I_] && !((EL2 >> LANE) & 1)) lds_min(&T[h[I_]], rent[I_]); })
+                        if (twins) { LDS_FENCE(); LANES({ if ((EL2 >> LANE) & 1) lds_max(&T[h[I_]], ent[I_]); }) }
                         LDS_FENCE();
-                        (void)actM;
-                        STAT(S_CYC_FIX, STAT_NOW() - tg2);
                         width = 64;
                         continue;
                     }
@@ -429,6 +518,7 @@ generic_batch:
             const unsigned long long tq0 = STAT_NOW(); (void)tq0;
             const int pre = (hasIns ? 1 : 0) + (hasRe ? 1 : 0);
             LV(int, q); LV(uint32_t, h); LV(uint32_t, old); LV(uint32_t, rb); LV(uint32_t, lo4);
+            LV(uint32_t, ent); LV(uint32_t, oldE);
             LV(int, ok);        // lane has a probe to make (not past the end-of-block stop, within width)
             LV(int, hit);
 
@@ -452,21 +542,24 @@ generic_batch:
                     const uint64_t s8 = ld64u(src + q[I_]);
                     lo4[I_] = (uint32_t)s8;
                     h[I_] = seq_hash<U16>(s8);
-                    old[I_] = tab_get<U16>(tab, h[I_]);
+                    ent[I_]  = ((uint32_t)q[I_] << sh) | (seq_tag(lo4[I_]) & tagMask);
+                    oldE[I_] = tab_get<U16>(tab, h[I_]);
+                    old[I_]  = oldE[I_] >> sh;
                 }
             })
             LDS_FENCE();
-            LANES({ if (LANE < nproc) tab_put<U16>(tab, h[I_], (uint32_t)q[I_]); })
+            LANES({ if (LANE < nproc) tab_put<U16>(tab, h[I_], ent[I_]); })
             LDS_FENCE();
-            LANES({ rb[I_] = (LANE < nproc) ? tab_get<U16>(tab, h[I_]) : (uint32_t)q[I_]; })
+            LANES({ rb[I_] = (LANE < nproc) ? tab_get<U16>(tab, h[I_]) : ent[I_]; })
             // candidate test (lz4.c:1090-1099); the insert-only lane never matches
             LANES({
                 if (LANE < nproc && !(hasIns && LANE == 0)) {
                     const uint32_t cur = (uint32_t)q[I_];
-                    if (U16 || old[I_] + kMaxDist >= cur) hit[I_] = (ld32u(src + old[I_]) == lo4[I_]);
+                    if ((U16 || old[I_] + kMaxDist >= cur) && ((oldE[I_] ^ ent[I_]) & tagMask) == 0)
+                        hit[I_] = (ld32u(src + old[I_]) == lo4[I_]);
                 }
             })
-            const uint64_t losers = BALLOT((LANE < nproc) && rb[I_] != (uint32_t)q[I_]);
+            const uint64_t losers = BALLOT((LANE < nproc) && rb[I_] != ent[I_]);
             const uint64_t hits   = BALLOT(hit[I_]);
 
             // collision-free prefix: lanes before the first lane that lost a same-slot store (lane 0 never has an earlier twin)
@@ -476,8 +569,8 @@ generic_batch:
             const int keep = hitsSafe ? ctz64(hitsSafe) + 1 : safe;          // lanes [0,keep) are really executed
 
             // ---- make the table exactly what the sequential parser would have left
-            LANES({ if (LANE >= keep && LANE < nproc) tab_put<U16>(tab, h[I_], old[I_]); })
-            if (losers) { LDS_FENCE(); LANES({ if (LANE < keep) tab_put<U16>(tab, h[I_], (uint32_t)q[I_]); }) }
+            LANES({ if (LANE >= keep && LANE < nproc) tab_put<U16>(tab, h[I_], oldE[I_]); })
+            if (losers) { LDS_FENCE(); LANES({ if (LANE < keep) tab_put<U16>(tab, h[I_], ent[I_]); }) }
             LDS_FENCE();
 
             if (!hitsSafe) {

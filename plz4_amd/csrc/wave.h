@@ -28,6 +28,8 @@
 #define LANES(...)     for (int lane_ = plz4_emu_first(); lane_ != plz4_emu_end(); lane_ += plz4_emu_step()) { __VA_ARGS__ }
 #define BALLOT(c)      ([&]() { uint64_t m_ = 0; for (int lane_ = 0; lane_ < 64; ++lane_) if (c) m_ |= 1ull << lane_; return m_; }())
 #define RL(x, w)       ((x)[(w)])
+#define WL(x, w, v)    do { const auto wl_v_ = (v); (x)[(w)] = wl_v_; } while (0)   /* write one lane (uniform lane index) */
+#define SHFL(x, l)     ((x)[(l) & 63])                  /* read another lane's value (per-lane lane index) */
 #define UNI(x)         (x)
 #define WAVE_FENCE()   do {} while (0)
 #define LDS_FENCE()    do {} while (0)
@@ -47,6 +49,9 @@ static inline int plz4_emu_step()  { return plz4_emu_descending ? -1 : 1; }
 #define LANES(...)     { __VA_ARGS__ }
 #define BALLOT(c)      ((uint64_t)__ballot((c)))
 #define RL(x, w)       plz4_readlane((x)[0], (w))
+/* v is evaluated by the whole wave BEFORE the select (it may contain ballots); then v_cmp + v_cndmask */
+#define WL(x, w, v)    do { const auto wl_v_ = (v); (x)[0] = (LANE == (w)) ? wl_v_ : (x)[0]; } while (0)
+#define SHFL(x, l)     plz4_bpermute((x)[0], (l))
 #define UNI(x)         plz4_readfirstlane((x))
 // Same-wave producer/consumer through memory needs no cache action on CDNA (one TCP, in-order VMEM
 // queue); the fence only stops the compiler from reordering the accesses.
@@ -61,6 +66,8 @@ __device__ __forceinline__ uint64_t plz4_readlane(uint64_t v, int l)
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
     return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ int      plz4_bpermute(int v, int l)      { return __builtin_amdgcn_ds_bpermute(l << 2, v); }
+__device__ __forceinline__ uint32_t plz4_bpermute(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_ds_bpermute(l << 2, (int)v); }
 __device__ __forceinline__ uint32_t plz4_readfirstlane(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int      plz4_readfirstlane(int v)      { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint8_t  plz4_readfirstlane(uint8_t v)  { return (uint8_t)__builtin_amdgcn_readfirstlane((int)v); }

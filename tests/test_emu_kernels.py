@@ -70,6 +70,12 @@ def test_emu_encode_4m(orc, emu, kind):
     _enc(orc, emu, data[bsz:], bsz)
 
 
+def test_emu_encode_over_4m(orc, emu):
+    """Blocks above 4 MiB (raw block API only) run the table without tags."""
+    src = synth.text((5 << 20) + 123, seed=9)
+    _enc(orc, emu, src, orc.bound(src.size))
+
+
 def _dec(orc, emu, comp, cap):
     a, da = orc.decompress_safe(comp, cap)
     b, db = emu.decompress_safe(comp, cap)

@@ -74,6 +74,12 @@ def test_gpu_encode_4m(orc, eng, kind):
     _check_encode(orc, eng, srcs[:1], [orc.bound(bsz)])         # block API: cap == bound (plz4_block.go:105)
 
 
+def test_gpu_encode_over_4m(orc, eng):
+    """Blocks above 4 MiB (raw block API only) run the table without tags."""
+    src = synth.text((5 << 20) + 123, seed=9)
+    _check_encode(orc, eng, [src], [orc.bound(src.size)])
+
+
 def _check_decode(orc, eng, comps, caps):
     res, outs = eng.decompress_batch(comps, caps)
     nbad = 0
