@@ -693,6 +693,80 @@ DEV int64_t read_more_len(const uint8_t* src, int* ip, int ilimit, bool initialC
     return len;
 }
 
+// Vector fast path of the decoder: 64 lanes look at the next 64 input bytes, each as if a sequence started at its
+// byte; a scalar hop follows the real token chain through the window while the sequences are "plain" (literal
+// run < 15, match length nibble < 15, literals inside the window, offset >= match length); output positions come
+// from a wave prefix sum; a plain sequence is kept only if its match source lies entirely before this batch's
+// output (so every copy of the batch is independent and issued together).  Everything else -- long lengths,
+// overlapping or near matches, bad offsets, the ends of the block -- is left to the exact sequential step of
+// wave_decode_block, which also owns liblz4's accept/reject rules.  Returns the number of sequences decoded.
+// Caller guarantees ip0 + 160 <= iend and op0 + 1088 <= oend (the reference is in its fast loop there).
+DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int* ipp, int64_t* opp)
+{
+    const int ip0 = *ipp; const int64_t op0 = *opp;
+    LV(uint32_t, b0); LV(int, ll); LV(int, ml); LV(int, off); LV(int, nxt); LV(int, outLen); LV(int, plain);
+    LANES({
+        const uint64_t w = ld64u(src + ip0 + LANE);
+        const uint32_t t = (uint32_t)(w & 0xFF);
+        const int l = (int)(t >> 4), mn = (int)(t & 15);
+        const int offAt = LANE + 1 + l;                      // window index of the offset's low byte
+        const uint32_t o16 = (l <= 5) ? (uint32_t)((w >> (8 * (1 + l))) & 0xFFFF) : (uint32_t)ld16u(src + ip0 + offAt);
+        b0[I_] = t; ll[I_] = l; ml[I_] = mn + kMinMatch; off[I_] = (int)o16;
+        nxt[I_] = offAt + 2; outLen[I_] = l + mn + kMinMatch;
+        plain[I_] = (l < 15) && (mn < 15) && (offAt <= 64) && (o16 >= (uint32_t)(mn + kMinMatch));
+    })
+    const uint64_t plainMask = BALLOT(plain[I_]);
+    uint64_t members = 0;
+    for (int cur = 0; cur < 64 && ((plainMask >> cur) & 1); cur = RL(nxt, cur)) members |= 1ull << cur;
+    if (!members) return 0;
+
+    // exclusive prefix sum of the members' output lengths -> where each sequence writes
+    LV(int, acc); LV(int, tmp); LV(int, outStart);
+    { const uint64_t mL = members; LANES({ acc[I_] = ((mL >> LANE) & 1) ? outLen[I_] : 0; }) }
+    for (int d = 1; d < 64; d <<= 1) {
+        LANES({ tmp[I_] = SHFL(acc, LANE >= d ? LANE - d : LANE); })
+        LANES({ if (LANE >= d) acc[I_] += tmp[I_]; })
+    }
+    {
+        const uint64_t mL = members;
+        LANES({ outStart[I_] = (int)op0 + acc[I_] - (((mL >> LANE) & 1) ? outLen[I_] : 0); })
+        // keep the prefix of sequences whose match source is valid and entirely older than this batch
+        const uint64_t bad = BALLOT(((mL >> LANE) & 1) &&
+                                    (outStart[I_] + ll[I_] - off[I_] < 0 || (int64_t)outStart[I_] + ll[I_] - off[I_] + ml[I_] > op0));
+        if (bad) members &= (1ull << ctz64(bad)) - 1;
+    }
+    if (!members) return 0;
+    const uint64_t mL = members;
+    // match bytes: every member lane copies its own 4..18 bytes (loads first, they never depend on this batch)
+    LANES({
+        if ((mL >> LANE) & 1) {
+            const uint8_t* s = dst + outStart[I_] + ll[I_] - off[I_];
+            uint8_t*       d = dst + outStart[I_] + ll[I_];
+            const v16u_t a = *(const v16u_t*)s;
+            const uint32_t b = ld16u(s + 16);
+            const uint64_t lo = (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), hi = (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32);
+            int rem = ml[I_]; uint64_t cur;
+            if (rem >= 16)     { *(v16u_t*)d = a; d += 16; rem -= 16; cur = b; }
+            else if (rem >= 8) { st64u(d, lo); d += 8; rem -= 8; cur = hi; }
+            else cur = lo;
+            if (rem & 4) { st32u(d, (uint32_t)cur); d += 4; cur >>= 32; }
+            if (rem & 2) { st16u(d, (uint16_t)cur); d += 2; cur >>= 16; }
+            if (rem & 1) { *d = (uint8_t)cur; }
+        }
+    })
+    // literal bytes: every window byte finds the member it follows
+    LANES({
+        const uint64_t upto = mL & ((LANE >= 63) ? ~0ull : ((2ull << LANE) - 1));
+        const int m  = upto ? 63 - __builtin_clzll(upto) : LANE;
+        const int os = SHFL(outStart, m), lm = SHFL(ll, m);
+        if (upto && LANE > m && LANE <= m + lm) dst[os + (LANE - m - 1)] = (uint8_t)b0[I_];
+    })
+    const int last = 63 - __builtin_clzll(members);
+    *ipp = ip0 + RL(nxt, last);
+    *opp = (int64_t)RL(outStart, last) + RL(outLen, last);
+    return __builtin_popcountll(members);
+}
+
 // LZ4_decompress_safe, full block, no dictionary.  Returns decoded size or liblz4's negative error code
 // -(input position)-1.  The reference's fast loop (>= 64 output bytes left) and safe loop reject at
 // different points, so both sets of tests are reproduced (see oracle/plz4_oracle.c for the same shape).
@@ -707,6 +781,10 @@ DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t*
     bool fast = (oend - op) >= 64;
 
     for (;;) {
+        if (fast && ip + 160 <= iend && op + 1088 <= oend) {
+            WAVE_FENCE();
+            if (wave_decode_plain_batch(src, dst, &ip, &op) > 0) { WAVE_FENCE(); continue; }
+        }
         const uint32_t token = UNI(src[ip]); ip++;
         int64_t ll = token >> 4, ml; int offset; int64_t mpos;
 

@@ -92,6 +92,7 @@ DEV uint32_t ld32u(const uint8_t* p) { return *(const u32u_t*)p; }
 DEV uint64_t ld64u(const uint8_t* p) { return *(const u64u_t*)p; }
 DEV void     st16u(uint8_t* p, uint16_t v) { *(u16u_t*)p = v; }
 DEV void     st32u(uint8_t* p, uint32_t v) { *(u32u_t*)p = v; }
+DEV void     st64u(uint8_t* p, uint64_t v) { *(u64u_t*)p = v; }
 
 DEV int ctz64(uint64_t v) { return __builtin_ctzll(v); }
 DEV uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
