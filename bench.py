@@ -31,6 +31,22 @@ POOL_BLOCKS = 16            # 64 MiB of unique T text generated on the host, til
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def committed_traffic(kernel: str, blocks: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_summary.json, scripts/gpu_profile.sh +
+    scripts/summarize_profile.py; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes).  None when no profile of this
+    exact workload size is committed -- PMC counters cannot be read from inside the timed process."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
+        try:
+            d = json.load(open(f))
+            if d.get("blocks_per_gpu") == blocks and "hbm_traffic_bytes_fetch_x2" in d["kernels"].get(kernel, {}):
+                best = {"bytes": d["kernels"][kernel]["hbm_traffic_bytes_fetch_x2"], "source": os.path.basename(f)}
+        except Exception:
+            pass
+    return best
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -53,26 +69,26 @@ def cpu_baseline(pool: np.ndarray, seconds: float = 12.0):
         enc = lambda s, d: ref.L.LZ4_compress_fast(s, d, BSZ, BSZ, 1)
         dec = lambda s, n, d: ref.L.LZ4_decompress_safe(s, d, n, BSZ + 8)
     cores = os.cpu_count() or 1
-    nblk = pool.size // BSZ
-    srcs = [np.ascontiguousarray(pool[i * BSZ:(i + 1) * BSZ]) for i in range(nblk)]
+    npool = pool.size // BSZ
+    nblk = max(npool, 2 * cores)                                             # at least two tasks per hardware thread
+    srcs = [np.ascontiguousarray(pool[(i % npool) * BSZ:(i % npool + 1) * BSZ]) for i in range(npool)]
     comp = [np.empty(BSZ + 8, dtype=np.uint8) for _ in range(nblk)]
-    outs = [np.empty(BSZ + 8, dtype=np.uint8) for _ in range(cores)]
+    outs = [np.empty(BSZ + 8, dtype=np.uint8) for _ in range(nblk)]
     clen = [0] * nblk
     u8p = orclib.u8p
 
     def do_enc(i):
-        s = srcs[i].ctypes.data_as(u8p); d = comp[i].ctypes.data_as(u8p)
+        s = srcs[i % npool].ctypes.data_as(u8p); d = comp[i].ctypes.data_as(u8p)
         c = enc(s, d)
         if c == 0:
-            comp[i][:BSZ] = srcs[i]; c = BSZ
+            comp[i][:BSZ] = srcs[i % npool]; c = BSZ
         clen[i] = c
         return orc.L.orc_xxh32(d, c)
 
-    def do_dec(args):
-        i, slot = args
+    def do_dec(i):
         d = comp[i].ctypes.data_as(u8p)
         orc.L.orc_xxh32(d, clen[i])
-        return dec(d, clen[i], outs[slot].ctypes.data_as(u8p))
+        return dec(d, clen[i], outs[i].ctypes.data_as(u8p))
 
     def timed(fn, items, threads):
         with ThreadPoolExecutor(threads) as ex:
@@ -83,14 +99,14 @@ def cpu_baseline(pool: np.ndarray, seconds: float = 12.0):
     t_start = time.perf_counter()
     while time.perf_counter() - t_start < seconds:
         t_enc += timed(do_enc, range(nblk), cores)
-        t_dec += timed(do_dec, [(i, i % cores) for i in range(nblk)], cores)
+        t_dec += timed(do_dec, range(nblk), cores)
         passes += 1
     mib = passes * nblk * BSZ / 2**20
-    t1e = timed(do_enc, range(min(nblk, 4)), 1); t1d = timed(do_dec, [(i, 0) for i in range(min(nblk, 4))], 1)
-    one = min(nblk, 4) * BSZ / 2**20
+    t1e = timed(do_enc, range(4), 1); t1d = timed(do_dec, range(4), 1)
+    one = 4 * BSZ / 2**20
     return {
         "value": round(mib / (t_enc + t_dec), 1), "unit": "MiB/s", "cores": cores, "kind": kind,
-        "sample": "%d passes over %d x 4MiB T blocks (%.0f MiB), one block per task on %d threads; "
+        "sample": "%d enc+dec passes over %d x 4MiB T blocks (%.0f MiB in all), one block per task on %d threads; "
                   "enc %.0f MiB/s, dec %.0f MiB/s; 1 thread: enc %.0f, dec %.0f MiB/s; LZ4 = %s, xxh32 = oracle C"
                   % (passes, nblk, mib, cores, mib / t_enc, mib / t_dec, one / t1e, one / t1d,
                      "vendored liblz4 1.10.0 (oracle/_ref)" if kind == "reference" else "oracle restatement"),
@@ -102,7 +118,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("PLZ4_BENCH_BLOCKS", "2560")),
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("PLZ4_BENCH_BLOCKS", "6144")),
                     help="4 MiB blocks per GPU per step")
     ap.add_argument("--kind", default="T")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -154,42 +170,18 @@ def main():
 
     gather = {}
 
+    def scatter(src, src_off, lens, dst_off, n, max_len, dst):
+        eng.dev_scatter_records(src.data_ptr(), src_off.data_ptr(), lens.data_ptr(), dst_off.data_ptr(), n, max_len,
+                                dst.data_ptr(), dst.numel(), stream)
+        gather.setdefault("live", []).append((src_off, lens, dst_off))      # keep operands alive until the step ends
+
     def frame_gather():
-        """N > 1: rank 0 owns the io.Writer.  All-gather the record sizes (tiny), send every body to rank 0 over
-        xGMI (RCCL send/recv), interleave there: global block g = j*N + r is record j of rank r."""
-        lens = torch.empty(world * B, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(lens, d_len)
-        lens = lens.view(world, B)
-        totals = lens.sum(dim=1, dtype=torch.int64)
-        if rank == 0:
-            tot = totals.cpu().tolist()
-            cap = max(tot)
-            if gather.get("cap", 0) < cap:
-                gather["buf"] = torch.empty((world - 1) * cap, dtype=torch.uint8, device=dev); gather["cap"] = cap
-                gather["frame"] = torch.empty(int(sum(tot) * 1.02) + (1 << 20), dtype=torch.uint8, device=dev)
-            cap = gather["cap"]
-            reqs = [dist.irecv(gather["buf"][(r - 1) * cap:(r - 1) * cap + tot[r]], src=r) for r in range(1, world)]
-            # offsets while the transfers fly: destination = exclusive scan in global (interleaved) order
-            inter = lens.t().contiguous().view(-1)                                  # [j*N + r]
-            dst_off = torch.cumsum(inter.to(torch.int64), 0) - inter
-            dst_off = dst_off.view(B, world).t().contiguous()                       # [r][j]
-            for r in range(world):
-                src_off = torch.cumsum(lens[r].to(torch.int64), 0) - lens[r]
-                if r == 0:
-                    eng.dev_scatter_records(d_body.data_ptr(), src_off.data_ptr(), lens[0].contiguous().data_ptr(),
-                                            dst_off[0].data_ptr(), B, BSZ + 8, gather["frame"].data_ptr(),
-                                            gather["frame"].numel(), stream)
-            for q in reqs:
-                q.wait()
-            for r in range(1, world):
-                src_off = torch.cumsum(lens[r].to(torch.int64), 0) - lens[r] + (r - 1) * cap
-                lr = lens[r].contiguous()
-                eng.dev_scatter_records(gather["buf"].data_ptr(), src_off.data_ptr(), lr.data_ptr(),
-                                        dst_off[r].data_ptr(), B, BSZ + 8, gather["frame"].data_ptr(),
-                                        gather["frame"].numel(), stream)
-        else:
-            total = int(totals[rank].item())
-            dist.send(d_body[:total], dst=0)
+        """N > 1: rank 0 owns the io.Writer.  All-gather the record sizes (tiny), send every body to rank 0 over xGMI
+        (RCCL send/recv), interleave there: global block g = j*N + r is record j of rank r (plz4_amd/shard.py)."""
+        from plz4_amd import shard
+        gather["live"] = []
+        total_local = int(d_off[-1].item())
+        shard.gather_frame_body(d_body[:max(total_local, 1)], d_len, rank, world, scatter, gather, BSZ + 8)
 
     def step(ev=None):
         if ev: ev[0].record()
@@ -275,6 +267,10 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_dec / HBM_PEAK_GBS, 5),
                                 "traffic": None},
         }
+        for key, kern in (("roofline", "k_encode_rec"), ("roofline_decode", "k_decode_rec")):
+            t = committed_traffic(kern, B)
+            if t:
+                out[key]["traffic"] = t["bytes"]; out[key]["traffic_source"] = t["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool)
         print(json.dumps(out), flush=True)
