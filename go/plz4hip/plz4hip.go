@@ -1,0 +1,162 @@
+//go:build cgo && plz4_hip
+
+// Package plz4hip is the cgo binding of the MI355X block engine (include/plz4hip.h, libplz4hip.so).
+// It takes the place of internal/pkg/clz4 (clz4.go:27-94) for the level-1, independent-block path.
+//
+// NOT COMPILED IN THE BUILD IMAGE (no Go toolchain there): this file is the binding a plz4 maintainer adds; every C entry
+// point it calls is exercised through the same ABI by tests/test_gpu_parity.py and tests/test_gpu_host.py.
+package plz4hip
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../plz4_amd -lplz4hip -Wl,-rpath,${SRCDIR}/../../plz4_amd
+#include <stdlib.h>
+#include "plz4hip.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"runtime"
+	"unsafe"
+)
+
+var (
+	ErrLz4Compress   = errors.New("lz4 fail compress; insufficient destination buffer") // == clz4.ErrLz4Compress
+	ErrLz4Decompress = errors.New("lz4 fail decompress")                                // == clz4.ErrLz4Decompress
+	ErrEngine        = errors.New("plz4hip engine failure")                             // never mapped to a stored block
+)
+
+// Ctx is one plz4hip_ctx (one device, internal staging, serialised by the library).
+type Ctx struct{ p *C.plz4hip_ctx }
+
+func NewCtx(device int) (*Ctx, error) {
+	var p *C.plz4hip_ctx
+	if rc := C.plz4hip_ctx_create(C.int(device), &p); rc != C.PLZ4HIP_OK {
+		return nil, fmt.Errorf("%w: plz4hip_ctx_create rc=%d", ErrEngine, int(rc))
+	}
+	c := &Ctx{p: p}
+	runtime.SetFinalizer(c, func(c *Ctx) { c.Close() })
+	return c, nil
+}
+
+func (c *Ctx) Close() {
+	if c.p != nil {
+		C.plz4hip_ctx_destroy(c.p)
+		c.p = nil
+	}
+}
+
+func CompressBound(sz int) int { return int(C.plz4hip_compress_bound(C.int(sz))) } // == clz4.CompressBound
+
+func (c *Ctx) engineErr(rc C.int) error {
+	return fmt.Errorf("%w: rc=%d: %s", ErrEngine, int(rc), C.GoString(C.plz4hip_last_error(c.p)))
+}
+
+// batch marshals [][]byte into the C pointer/length arrays.  The pointer arrays live in C memory (cgo forbids Go
+// pointers to Go pointers); the Go slices are pinned for the duration of the call (Go 1.21 runtime.Pinner).
+type batch struct {
+	ptrs unsafe.Pointer
+	lens []C.int32_t
+	pin  runtime.Pinner
+}
+
+func newBatch(bufs [][]byte, useCap bool) *batch {
+	n := len(bufs)
+	b := &batch{ptrs: C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))), lens: make([]C.int32_t, n)}
+	pp := unsafe.Slice((*unsafe.Pointer)(b.ptrs), n)
+	for i, s := range bufs {
+		if useCap {
+			s = s[:cap(s)]
+		}
+		b.lens[i] = C.int32_t(len(s))
+		if len(s) > 0 {
+			b.pin.Pin(&s[0])
+			pp[i] = unsafe.Pointer(&s[0])
+		} else {
+			pp[i] = nil
+		}
+	}
+	return b
+}
+func (b *batch) free() { b.pin.Unpin(); C.free(b.ptrs) }
+
+// CompressBatch == clz4.CompressFast(src[i], dst[i], 1) for every i (clz4.go:31-45).
+// n[i] > 0 bytes written, n[i] == 0 => ErrLz4Compress for that block (the caller stores it raw, blk.go:78-92).
+func (c *Ctx) CompressBatch(src, dst [][]byte, level int) ([]int, error) {
+	s, d := newBatch(src, false), newBatch(dst, false)
+	defer s.free()
+	defer d.free()
+	res := make([]C.int32_t, len(src))
+	rc := C.plz4hip_compress_batch(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(d.ptrs), &d.lens[0], C.int(level), &res[0])
+	if rc != C.PLZ4HIP_OK {
+		return nil, c.engineErr(rc)
+	}
+	out := make([]int, len(res))
+	for i, r := range res {
+		out[i] = int(r)
+	}
+	return out, nil
+}
+
+// DecompressBatch == clz4.DecompressSafe(src[i], dst[i]) for every i (clz4.go:47-60): n[i] < 0 is liblz4's code.
+func (c *Ctx) DecompressBatch(src, dst [][]byte) ([]int, error) {
+	s, d := newBatch(src, false), newBatch(dst, false)
+	defer s.free()
+	defer d.free()
+	res := make([]C.int32_t, len(src))
+	rc := C.plz4hip_decompress_batch(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(d.ptrs), &d.lens[0], &res[0])
+	if rc != C.PLZ4HIP_OK {
+		return nil, c.engineErr(rc)
+	}
+	out := make([]int, len(res))
+	for i, r := range res {
+		out[i] = int(r)
+	}
+	return out, nil
+}
+
+// EncodeRecords == blk.CompressToBlk for every block (blk.go:69-109): rec[i] must have cap bsz+8; returns record lengths.
+func (c *Ctx) EncodeRecords(src, rec [][]byte, bsz, level int, blockChecksum bool) ([]int, error) {
+	s, r := newBatch(src, false), newBatch(rec, true)
+	defer s.free()
+	defer r.free()
+	res := make([]C.int32_t, len(src))
+	bc := C.int(0)
+	if blockChecksum {
+		bc = 1
+	}
+	rc := C.plz4hip_encode_records(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], C.int(bsz), C.int(level), bc, (**C.void)(r.ptrs), &res[0])
+	if rc != C.PLZ4HIP_OK {
+		return nil, c.engineErr(rc)
+	}
+	out := make([]int, len(res))
+	for i, v := range res {
+		out[i] = int(v)
+	}
+	return out, nil
+}
+
+// DecodeRecords == FrameReader checks + BlkT.Decompress for every record (blk/frame.go:54-127, blk.go:50-61).
+// status[i]: 0 ok, 1 ErrBlockHash, 2 ErrBlockSizeOverflow, 3 ErrDecompress (n[i] then holds liblz4's code).
+func (c *Ctx) DecodeRecords(rec, dst [][]byte, bsz int, blockChecksum bool) (n []int, status []int, err error) {
+	r, d := newBatch(rec, false), newBatch(dst, true)
+	defer r.free()
+	defer d.free()
+	res := make([]C.int32_t, len(rec))
+	st := make([]C.int32_t, len(rec))
+	bc := C.int(0)
+	if blockChecksum {
+		bc = 1
+	}
+	rc := C.plz4hip_decode_records(c.p, C.int(len(rec)), (**C.void)(r.ptrs), &r.lens[0], C.int(bsz), bc, (**C.void)(d.ptrs), &res[0], &st[0])
+	if rc != C.PLZ4HIP_OK {
+		return nil, nil, c.engineErr(rc)
+	}
+	n, status = make([]int, len(res)), make([]int, len(res))
+	for i := range res {
+		n[i], status[i] = int(res[i]), int(st[i])
+	}
+	return
+}
