@@ -100,6 +100,35 @@ int plz4hip_decode_records(plz4hip_ctx* ctx, int nBlocks,
                            void* const* dst, int32_t* result, int32_t* status);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * B'. Dictionaries and linked blocks (level 1; SURVEY.md §8a-11, BASELINE config 5).
+ *    plz4hip_dict == clz4.DictCtx (clz4.go:96-120: private copy of the last 64 KiB + the LZ4_loadDictSlow table).
+ *    *_batch_dict : clz4.StreamIndieCtx.Compress (clz4.go:160-179) / clz4.DecompressSafeWithDict (clz4.go:62-78) per block,
+ *                   i.e. CompressBlock/DecompressBlock with WithBlockDictionary (plz4_block.go:48-53).
+ *    encode_records_ex: `dict` = WithDictionary; `linked` = WithBlockLinked: block i>0 is primed with the last <= 64 KiB of
+ *                   src[i-1] (async/writer.go:412-437 -> LZ4_loadDict, clz4.go:224-241); block 0 with prevTail when the
+ *                   batch continues a frame (prevTail == NULL: block 0 starts the frame and uses `dict`, if any).
+ *    decode_records_ex: independent blocks + dict: every block against `dict` (compress/decompress.go:42-58);
+ *                   linked: a serial chain over the batch; `window` (64 KiB, caller-owned) / `*windowLen` carry
+ *                   compress.DictT (compress/dict.go:5-56) across calls: initialise with the dictionary's last 64 KiB
+ *                   (or length 0).  As in the reference, a stored block does not update the window.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct plz4hip_dict plz4hip_dict;
+int  plz4hip_dict_create(plz4hip_ctx* ctx, const void* dict, int dictLen, plz4hip_dict** out);
+void plz4hip_dict_destroy(plz4hip_ctx* ctx, plz4hip_dict* dict);
+
+int plz4hip_compress_batch_dict(plz4hip_ctx* ctx, int nBlocks, const void* const* src, const int32_t* srcLen,
+                                void* const* dst, const int32_t* dstCap, int level, const plz4hip_dict* dict, int32_t* result);
+int plz4hip_decompress_batch_dict(plz4hip_ctx* ctx, int nBlocks, const void* const* src, const int32_t* srcLen,
+                                  void* const* dst, const int32_t* dstCap, const plz4hip_dict* dict, int32_t* result);
+
+int plz4hip_encode_records_ex(plz4hip_ctx* ctx, int nBlocks, const void* const* src, const int32_t* srcLen,
+                              int bsz, int level, int blockChecksum, int linked, const plz4hip_dict* dict,
+                              const void* prevTail, int prevTailLen, void* const* rec, int32_t* recLen);
+int plz4hip_decode_records_ex(plz4hip_ctx* ctx, int nBlocks, const void* const* rec, const int32_t* recLen,
+                              int bsz, int blockChecksum, int linked, const plz4hip_dict* dict,
+                              void* window, int* windowLen, void* const* dst, int32_t* result, int32_t* status);
+
+/* ---------------------------------------------------------------------------------------------------------
  * C. Device-resident pipeline (bench.py, GPU-to-GPU producers).  Every pointer below is a DEVICE pointer
  *    on ctx's device; work is enqueued on `stream` (a hipStream_t; NULL is HIP's default/null stream, as for any
  *    hip*Async call) and the call returns without synchronising.  Layout:

@@ -19,7 +19,8 @@ SYMBOLS = [
     "plz4hip_xxh32_batch", "plz4hip_encode_records", "plz4hip_decode_records", "plz4hip_dev_stage_stride",
     "plz4hip_dev_encode_records", "plz4hip_dev_compact_records", "plz4hip_dev_scatter_records",
     "plz4hip_dev_decode_records", "plz4hip_dev_compress", "plz4hip_dev_decompress",
-    "plz4hip_dev_resident_waves",
+    "plz4hip_dev_resident_waves", "plz4hip_dict_create", "plz4hip_dict_destroy", "plz4hip_compress_batch_dict",
+    "plz4hip_decompress_batch_dict", "plz4hip_encode_records_ex", "plz4hip_decode_records_ex",
 ]
 
 E_NAMES = {0: "OK", -1: "E_ARG", -2: "E_DEVICE", -3: "E_NOMEM", -4: "E_UNSUPPORTED"}
@@ -88,6 +89,17 @@ def load():
     L.plz4hip_dev_decompress.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp, vp, vp]
     L.plz4hip_dev_resident_waves.restype = C.c_int
     L.plz4hip_dev_resident_waves.argtypes = [vp, C.c_int]
+    L.plz4hip_dict_create.restype = C.c_int
+    L.plz4hip_dict_create.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.plz4hip_dict_destroy.argtypes = [vp, vp]
+    L.plz4hip_compress_batch_dict.restype = C.c_int
+    L.plz4hip_compress_batch_dict.argtypes = [vp, C.c_int, pp, i32p, pp, i32p, C.c_int, vp, i32p]
+    L.plz4hip_decompress_batch_dict.restype = C.c_int
+    L.plz4hip_decompress_batch_dict.argtypes = [vp, C.c_int, pp, i32p, pp, i32p, vp, i32p]
+    L.plz4hip_encode_records_ex.restype = C.c_int
+    L.plz4hip_encode_records_ex.argtypes = [vp, C.c_int, pp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, pp, i32p]
+    L.plz4hip_decode_records_ex.restype = C.c_int
+    L.plz4hip_decode_records_ex.argtypes = [vp, C.c_int, pp, i32p, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int), pp, i32p, i32p]
     if L.plz4hip_abi_version() != ABI_VERSION:
         raise ImportError("plz4_amd: libplz4hip.so ABI %d != binding %d" % (L.plz4hip_abi_version(), ABI_VERSION))
     _lib = L
@@ -188,6 +200,46 @@ class Engine:
         self._chk(self.L.plz4hip_decode_records(self.h, n, _ptr_array(recs), _i32p(lens), bsz, int(block_checksum),
                                                 _ptr_array(dsts), _i32p(res), _i32p(st)))
         return res, st, [d[:max(int(r), 0)] for d, r in zip(dsts, res)]
+
+    # ---- B'. dictionaries / linked blocks
+    def dict_create(self, dct: np.ndarray):
+        h = C.c_void_p()
+        self._chk(self.L.plz4hip_dict_create(self.h, dct.ctypes.data if dct.size else None, dct.size, C.byref(h)))
+        return h
+
+    def dict_destroy(self, d):
+        self.L.plz4hip_dict_destroy(self.h, d)
+
+    def compress_batch_dict(self, srcs, caps, d):
+        n = len(srcs); lens = _i32([s.size for s in srcs]); capa = _i32(caps)
+        dsts = [np.empty(max(int(c), 1), dtype=np.uint8) for c in caps]; res = np.zeros(n, dtype=np.int32)
+        self._chk(self.L.plz4hip_compress_batch_dict(self.h, n, _ptr_array(srcs), _i32p(lens), _ptr_array(dsts), _i32p(capa), 1, d, _i32p(res)))
+        return res, [x[:max(int(r), 0)] for x, r in zip(dsts, res)]
+
+    def decompress_batch_dict(self, srcs, caps, d):
+        n = len(srcs); lens = _i32([s.size for s in srcs]); capa = _i32(caps)
+        dsts = [np.zeros(max(int(c), 1), dtype=np.uint8) for c in caps]; res = np.zeros(n, dtype=np.int32)
+        self._chk(self.L.plz4hip_decompress_batch_dict(self.h, n, _ptr_array(srcs), _i32p(lens), _ptr_array(dsts), _i32p(capa), d, _i32p(res)))
+        return res, [x[:max(int(r), 0)] for x, r in zip(dsts, res)]
+
+    def encode_records_ex(self, srcs, bsz, block_checksum, linked=False, d=None, prev_tail=None):
+        n = len(srcs); lens = _i32([s.size for s in srcs])
+        recs = [np.empty(bsz + 8, dtype=np.uint8) for _ in range(n)]; rl = np.zeros(n, dtype=np.int32)
+        pt = prev_tail.ctypes.data if (prev_tail is not None and prev_tail.size) else (np.zeros(1, np.uint8).ctypes.data if prev_tail is not None else None)
+        self._keep_pt = prev_tail
+        self._chk(self.L.plz4hip_encode_records_ex(self.h, n, _ptr_array(srcs), _i32p(lens), bsz, 1, int(block_checksum), int(linked), d,
+                                                   pt, 0 if prev_tail is None else prev_tail.size, _ptr_array(recs), _i32p(rl)))
+        return [r[:int(k)] for r, k in zip(recs, rl)]
+
+    def decode_records_ex(self, recs, bsz, block_checksum, linked=False, d=None, window=None, window_len=0):
+        n = len(recs); lens = _i32([r.size for r in recs])
+        dsts = [np.zeros(bsz + 8, dtype=np.uint8) for _ in range(n)]
+        res = np.zeros(n, dtype=np.int32); st = np.zeros(n, dtype=np.int32)
+        wl = C.c_int(window_len)
+        self._chk(self.L.plz4hip_decode_records_ex(self.h, n, _ptr_array(recs), _i32p(lens), bsz, int(block_checksum), int(linked), d,
+                                                   window.ctypes.data if window is not None else None, C.byref(wl),
+                                                   _ptr_array(dsts), _i32p(res), _i32p(st)))
+        return res, st, [x[:max(int(r), 0)] for x, r in zip(dsts, res)], wl.value
 
     # ---- C. device-resident pipeline (raw device pointers; torch tensors supply .data_ptr())
     def dev_encode_records(self, src_ptr, src_bytes, bsz, block_checksum, stage_ptr, reclen_ptr, stream=0, level: int = 1):

@@ -661,6 +661,220 @@ DEV int wave_encode_block(const uint8_t* __restrict__ src, int n, uint8_t* __res
     return wave_encode_block_tt<false>(src, n, dst, cap, limited, tab);
 }
 
+// ------------------------------------------------------------------------------------------ encoder, dictionary modes
+// LZ4_compress_fast_continue as plz4 drives it (clz4.go:160-179 StreamIndieCtx, :224-248 StreamLinkedCtx; lz4.c:1707-1783):
+// always byU32 + limitedOutput.  Which flavour of lz4.c:930-1338 runs depends on how the stream was primed:
+enum : int {
+    kDictFreshPrefix = 0,   // linked block 0, no dictionary: withPrefix64k, empty prefix, indices start at 0
+    kDictLoad        = 1,   // linked block k>0: LZ4_loadDict(previous block's last <=64 KiB) then usingExtDict (dictSmall if < 64 KiB)
+    kDictCtxCopy     = 2,   // dictionary context attached, n > 4 KiB: its table is copied in, usingExtDict, noDictIssue
+    kDictCtxLookup   = 3,   // dictionary context attached, n <= 4 KiB: usingDictCtx (own empty table + the context's table)
+    kDictNonePrefix  = 4    // a dictionary shorter than 8 bytes is dropped by LZ4_loadDict: withPrefix64k, indices start at 64 KiB, dictSmall
+};
+struct DictEnc {
+    const uint8_t*  dict;       // the (<= 64 KiB) dictionary bytes in device memory; nullptr in modes 0 and 4
+    int             dictSize;
+    int             mode;
+    const uint32_t* dictTable;  // modes 2 and 3: the 4096-entry table LZ4_loadDictSlow builds (prepared on the host, clz4.go:96-120)
+};
+
+// 8 bytes at p of which only `valid` may be touched
+DEV uint64_t ld64p_guard(const uint8_t* p, int valid)
+{
+    if (valid >= 8) return ld64u(p);
+    uint64_t v = 0;
+    for (int b = 0; b < valid; ++b) v |= (uint64_t)p[b] << (8 * b);
+    return v;
+}
+// number of equal bytes of a[0..) and b[0..), at most maxLen (== LZ4_count with pInLimit = a + maxLen)
+DEV int wave_count_ptr(const uint8_t* a, const uint8_t* b, int maxLen)
+{
+    int total = 0;
+    for (;;) {
+        LV(uint64_t, d);
+        LANES({
+            const int off = total + 8 * LANE;
+            const int valid = maxLen - off;
+            if (valid <= 0) d[I_] = ~0ull;
+            else {
+                uint64_t x = ld64p_guard(a + off, valid) ^ ld64p_guard(b + off, valid);
+                if (valid < 8) x |= ~0ull << (8 * valid);
+                d[I_] = x;
+            }
+        })
+        const uint64_t stop = BALLOT(d[I_] != 0);
+        if (stop) { const int l = ctz64(stop); return total + 8 * l + (ctz64(RL(d, l)) >> 3); }
+        total += 512;
+    }
+}
+// equal bytes going backwards from a[-1], b[-1], at most maxBack
+DEV int wave_back_ptr(const uint8_t* a, const uint8_t* b, int maxBack)
+{
+    int total = 0;
+    while (total < maxBack) {
+        const uint64_t neq = BALLOT((total + LANE >= maxBack) || (a[-1 - total - LANE] != b[-1 - total - LANE]));
+        if (neq) return total + ctz64(neq);
+        total += 64;
+    }
+    return maxBack;
+}
+
+DEV int wave_encode_block_dict(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap,
+                               const DictEnc dc, void* tab)
+{
+    if ((uint32_t)n > (uint32_t)kMaxInput) return 0;
+    if (n == 0) { if (cap <= 0) return 0; LANES({ if (LANE == 0) dst[0] = 0; }) return 1; }     // lz4.c:1361-1371 (always limitedOutput)
+
+    uint32_t* T = (uint32_t*)tab;
+    const int       mode       = dc.mode;
+    const uint32_t  startIndex = (mode == kDictFreshPrefix) ? 0u : 65536u;
+    const bool      extMem     = (mode == kDictLoad || mode == kDictCtxCopy || mode == kDictCtxLookup);
+    const uint32_t  dictSize   = extMem ? (uint32_t)dc.dictSize : 0u;
+    const uint8_t*  dictEnd    = extMem ? dc.dict + dc.dictSize : nullptr;
+    const bool      dictSmall  = (mode == kDictNonePrefix) || (mode == kDictLoad && dictSize < 65536u);
+    const uint32_t  prefixIdxLimit = startIndex - dictSize;                                      // lz4.c:959
+
+    // ---- prime the table
+    if (mode == kDictCtxCopy) {
+        LANES({ for (int i = LANE; i < kHashBytes / 4; i += 64) T[i] = dc.dictTable[i]; })        // LZ4_memcpy(streamPtr, dictCtx), lz4.c:1767
+    } else {
+        LANES({ for (int i = LANE; i < kHashBytes / 4; i += 64) T[i] = 0; })
+        if (mode == kDictLoad) {
+            LDS_FENCE();
+            // LZ4_loadDict (lz4.c:1621-1628): every 3rd position, later entries overwrite earlier ones == max index per slot
+            const int cnt = (dc.dictSize - 8) / 3 + 1;
+            const uint32_t idx0 = 65536u - dictSize;
+            LANES({ for (int k = LANE; k < cnt; k += 64) lds_max(&T[seq_hash<false>(ld64u(dc.dict + 3 * k))], idx0 + 3u * (uint32_t)k); })
+        }
+    }
+    LDS_FENCE();
+
+    const int lastProbe  = n - kMfLimit + 1;
+    const int matchLimit = n - kLastLiterals;
+    int anchor = 0, op = 0;
+
+    if (n >= kMinLength) {
+        int  insPos = 0;  bool hasIns = true;
+        int  rePos  = 0;  bool hasRe  = false;
+        int  sBase  = 1;  int  sIter  = 0;
+        int  width  = 16;
+        for (;;) {
+            const int pre = (hasIns ? 1 : 0) + (hasRe ? 1 : 0);
+            LV(int, q); LV(uint32_t, h); LV(uint32_t, old); LV(uint32_t, rb); LV(uint32_t, lo4); LV(uint32_t, cidx);
+            LV(int, ok); LV(int, hit); LV(int, inD);
+            LANES({
+                const int k = LANE - pre;
+                int pos, stride, fine = 1;
+                if (k < 0) { pos = (hasIns && LANE == 0) ? insPos : rePos; }
+                else { probe_pos(sBase, sIter + k, &pos, &stride); fine = (pos + stride <= lastProbe); }
+                q[I_] = pos; ok[I_] = fine && (LANE < width);
+            })
+            const uint64_t okMask = BALLOT(ok[I_]);
+            const int nproc = (~okMask) ? ctz64(~okMask) : 64;
+            const bool endInBatch = nproc < width;
+
+            LANES({
+                hit[I_] = 0; inD[I_] = 0; cidx[I_] = 0;
+                if (LANE < nproc) {
+                    const uint64_t s8 = ld64u(src + q[I_]);
+                    lo4[I_] = (uint32_t)s8;
+                    h[I_] = seq_hash<false>(s8);
+                    old[I_] = T[h[I_]];
+                }
+            })
+            LDS_FENCE();
+            LANES({ if (LANE < nproc) T[h[I_]] = (uint32_t)q[I_] + startIndex; })
+            LDS_FENCE();
+            LANES({ rb[I_] = (LANE < nproc) ? T[h[I_]] : (uint32_t)q[I_] + startIndex; })
+            // candidate by dictionary mode (lz4.c:1058-1099)
+            LANES({
+                if (LANE < nproc && !(hasIns && LANE == 0)) {
+                    const uint32_t cur = (uint32_t)q[I_] + startIndex;
+                    uint32_t mi = old[I_];
+                    const uint8_t* mp;
+                    if (extMem && mi < startIndex) {
+                        if (mode == kDictCtxLookup) mi = dc.dictTable[h[I_]];                    // dictCtx->currentOffset == 64 KiB == startIndex
+                        mp = dictEnd - (startIndex - mi);
+                        inD[I_] = 1;
+                    } else {
+                        mp = src + (mi - startIndex);
+                    }
+                    cidx[I_] = mi;
+                    if (!(dictSmall && mi < prefixIdxLimit) && mi + kMaxDist >= cur) hit[I_] = (ld32u(mp) == lo4[I_]);
+                }
+            })
+            const uint64_t losers = BALLOT((LANE < nproc) && rb[I_] != (uint32_t)q[I_] + startIndex);
+            const uint64_t hits   = BALLOT(hit[I_]);
+            int safe = nproc;
+            if (losers) safe = min_(nproc, max_(ctz64(losers), 1));
+            const uint64_t hitsSafe = hits & ((safe >= 64) ? ~0ull : ((1ull << safe) - 1));
+            const int keep = hitsSafe ? ctz64(hitsSafe) + 1 : safe;
+            LANES({ if (LANE >= keep && LANE < nproc) T[h[I_]] = old[I_]; })
+            if (losers) { LDS_FENCE(); LANES({ if (LANE < keep) T[h[I_]] = (uint32_t)q[I_] + startIndex; }) }
+            LDS_FENCE();
+
+            if (!hitsSafe) {
+                int used = keep;
+                if (hasIns && used > 0) { hasIns = false; used--; }
+                if (hasRe  && used > 0) { hasRe = false; used--; }
+                sIter += used;
+                if (keep == nproc && endInBatch && !hasIns && !hasRe) break;
+                width = 64;
+                continue;
+            }
+            const int  w     = keep - 1;
+            const bool isRe  = hasRe && (w == pre - 1);
+            int        p     = RL(q, w);
+            const uint32_t mi = RL(cidx, w);
+            const bool inDict = RL(inD, w) != 0;
+            const uint32_t offset = (uint32_t)p + startIndex - mi;                               // lz4.c:1097 (before catch-up; unchanged by it)
+            const uint8_t* mp    = inDict ? dictEnd - (startIndex - mi) : src + (mi - startIndex);
+            const uint8_t* floor = inDict ? dc.dict : src;                                       // lowLimit (lz4.c:1065-1079)
+
+            if (!isRe) {
+                const int back = wave_back_ptr(src + p, mp, min_(p - anchor, (int)(mp - floor)));
+                p -= back; mp -= back;
+            }
+            const int lit = p - anchor;
+            const int tokPos = op++;
+            if (!isRe && (int64_t)op + lit + (2 + 1 + kLastLiterals) + lit / 255 > cap) return 0;
+            if (lit >= 15) op = emit_len_ext(dst, op, lit - 15);
+            wave_copy(dst + op, src + anchor, lit);
+            op += lit;
+            LANES({ if (LANE == 0) st16u(dst + op, (uint16_t)offset); })
+            op += 2;
+            int mc, ip;
+            if (inDict) {                                                                        // lz4.c:1168-1180
+                int lim = p + (int)(dictEnd - mp);
+                if (lim > matchLimit) lim = matchLimit;
+                mc = wave_count_ptr(src + p + kMinMatch, mp + kMinMatch, lim - (p + kMinMatch));
+                ip = p + kMinMatch + mc;
+                if (ip == lim) { const int more = wave_count_ptr(src + lim, src, matchLimit - lim); mc += more; ip += more; }
+            } else {
+                mc = wave_count_ptr(src + p + kMinMatch, mp + kMinMatch, matchLimit - (p + kMinMatch));
+                ip = p + kMinMatch + mc;
+            }
+            if ((int64_t)op + (1 + kLastLiterals) + (mc + 240) / 255 > cap) return 0;
+            LANES({ if (LANE == 0) dst[tokPos] = (uint8_t)((min_(lit, 15) << 4) | min_(mc, 15)); })
+            if (mc >= 15) op = emit_len_ext(dst, op, mc - 15);
+            anchor = ip;
+            if (ip >= lastProbe) break;
+            hasIns = true; insPos = ip - 2;
+            hasRe = true;  rePos = ip;
+            sBase = ip + 1; sIter = 0; width = 16;
+        }
+    }
+    {
+        const int last = n - anchor;
+        if ((int64_t)op + last + 1 + (last + 255 - 15) / 255 > cap) return 0;
+        if (last >= 15) { LANES({ if (LANE == 0) dst[op] = 0xF0; }) op = emit_len_ext(dst, op + 1, last - 15); }
+        else { LANES({ if (LANE == 0) dst[op] = (uint8_t)(last << 4); }) op++; }
+        wave_copy(dst + op, src + anchor, last);
+        op += last;
+    }
+    return op;
+}
+
 // ------------------------------------------------------------------------------------------ decoder
 // Match copy inside the output: dst[op+i] = dst[op-offset+i], i < len, with LZ4's overlap semantics
 // (offset < len replicates the pattern).  offset 0 zero-fills, like both liblz4 copy routines do
@@ -770,9 +984,16 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
 // LZ4_decompress_safe, full block, no dictionary.  Returns decoded size or liblz4's negative error code
 // -(input position)-1.  The reference's fast loop (>= 64 output bytes left) and safe loop reject at
 // different points, so both sets of tests are reproduced (see oracle/plz4_oracle.c for the same shape).
-DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap)
+// With a dictionary (LZ4_decompress_safe_usingDict, lz4.c:2719-2732 -> forceExtDict): matches may start in `dict`
+// (<= 64 KiB, not adjacent to dst) and run on into the block (lz4.c:2166-2196, :2358-2384).
+DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap,
+                          const uint8_t* dict = nullptr, const int dictLen = 0)
 {
     if (src == nullptr || cap < 0) return -1;
+    const bool ext = (dict != nullptr && dictLen > 0);
+    const int64_t dictSize = ext ? dictLen : 0;
+    const uint8_t* const dictEnd = ext ? dict + dictLen : nullptr;
+    const bool checkOffset = dictSize < 65536;                                   // lz4.c:2047
     const int iend = n;
     const int64_t oend = cap;
     int ip = 0; int64_t op = 0;
@@ -814,7 +1035,11 @@ DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t*
                 ml += kMinMatch;
                 if (op + ml >= oend - 64) { fast = false; goto safe_match; }
             }
-            if (mpos < 0) return -ip - 1;                                   // checkOffset, lz4.c:2161
+            if (checkOffset && mpos + dictSize < 0) return -ip - 1;         // lz4.c:2161
+            if (ext && mpos < 0) {
+                if (op + ml > oend - kLastLiterals) return -ip - 1;         // lz4.c:2168-2175
+                goto dict_copy;
+            }
             WAVE_FENCE();
             wave_copy_match(dst, op, offset, (int)ml);
             WAVE_FENCE();
@@ -862,12 +1087,33 @@ match_len:
         }
         ml += kMinMatch;
 safe_match:
-        if (mpos < 0) return -ip - 1;                                       // lz4.c:2356
+        if (checkOffset && mpos + dictSize < 0) return -ip - 1;             // lz4.c:2356
+        if (ext && mpos < 0) {
+            if (op + ml > oend - kLastLiterals) return -ip - 1;             // lz4.c:2360-2363
+            goto dict_copy;
+        }
         if (op + ml > oend - kLastLiterals) return -ip - 1;                 // lz4.c:2421-2423
         WAVE_FENCE();
         wave_copy_match(dst, op, offset, (int)ml);
         WAVE_FENCE();
         op += ml;
+        continue;
+dict_copy:                                                                   // lz4.c:2177-2195 == :2365-2383
+        {
+            const int back = (int)(-mpos);                                   // bytes of the match that lie in the dictionary
+            WAVE_FENCE();
+            if (ml <= back) {
+                wave_copy(dst + op, dictEnd - back, (int)ml);
+                op += ml;
+            } else {
+                wave_copy(dst + op, dictEnd - back, back);
+                op += back;
+                WAVE_FENCE();
+                wave_copy_match(dst, op, (int)op, (int)(ml - back));         // the rest comes from the start of the block
+                op += ml - back;
+            }
+            WAVE_FENCE();
+        }
     }
     return (int)op;
 }

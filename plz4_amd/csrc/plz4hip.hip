@@ -32,6 +32,12 @@ struct CodecArgs {
     uint32_t*      queue;
     int            nBlocks;
     int            blockChecksum;
+    // dictionary / linked blocks
+    const uint8_t*  dict;       int dictLen;        // last <= 64 KiB of the user dictionary (device), or null
+    const uint32_t* dictTable;                      // LZ4_loadDictSlow table of that dictionary
+    int             linked;                         // encode: block i>0 is primed with the tail of block i-1
+    const uint8_t*  prevTail;   int prevTailLen;    // linked: window of block 0 (-1: block 0 starts a frame)
+    uint8_t*        window;     int* windowLen;     // linked decode: the 64 KiB sliding dictionary (2 x 64 KiB ping-pong), in/out
 };
 
 __device__ __forceinline__ int next_block(uint32_t* q)
@@ -83,6 +89,136 @@ __global__ __launch_bounds__(64) void k_encode_rec(CodecArgs a)
             len += 4;
         }
         if ((threadIdx.x & 63u) == 0) { st32u(rec, word); a.result[i] = len; }
+    }
+}
+
+// blk.CompressToBlk with a dictionary and/or linked blocks (config 5).  Which stream priming applies to a block follows
+// clz4.go:160-179 (StreamIndieCtx) and :224-248 (StreamLinkedCtx) + async/writer.go:412-437 (_genDict).
+__global__ __launch_bounds__(64) void k_encode_rec_dict(CodecArgs a)
+{
+    __shared__ uint32_t lds[kHashBytes / 4];
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int      n   = block_len(a, i);
+        const uint8_t* s   = a.src + (int64_t)i * a.srcStride;
+        uint8_t*       rec = a.dst + (int64_t)i * a.dstStride;
+        DictEnc dc{nullptr, 0, kDictFreshPrefix, nullptr};
+        const uint8_t* tail = nullptr; int tailLen = -1;
+        if (a.linked) {
+            if (i > 0) { const int pl = block_len(a, i - 1); tailLen = pl < 65536 ? pl : 65536; tail = a.src + (int64_t)(i - 1) * a.srcStride + (pl - tailLen); }
+            else if (a.prevTailLen >= 0) { tail = a.prevTail; tailLen = a.prevTailLen; }
+        }
+        if (tailLen >= 0) {                                   // linked block after another block: LZ4_loadDict(previous tail)
+            dc.mode = tailLen >= 8 ? kDictLoad : kDictNonePrefix;
+            if (tailLen >= 8) { dc.dict = tail; dc.dictSize = tailLen; }
+        } else if (a.dict != nullptr || a.dictLen >= 0) {     // a dictionary context is attached (possibly an empty one)
+            if (a.dictLen >= 8) { dc.dict = a.dict; dc.dictSize = a.dictLen; dc.dictTable = a.dictTable; dc.mode = n > 4096 ? kDictCtxCopy : kDictCtxLookup; }
+            else dc.mode = kDictNonePrefix;
+        }                                                     // else: linked frame start without dictionary -> kDictFreshPrefix
+        int      c    = wave_encode_block_dict(s, n, rec + 4, a.bsz, dc, lds);
+        uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
+        if (c == 0) { wave_copy(rec + 4, s, n); c = n; word = 0x80000000u | ((uint32_t)n & 0x7FFFFFFFu); }
+        int len = c + 4;
+        if (a.blockChecksum) {
+            WAVE_FENCE();
+            const uint32_t x = wave_xxh32(rec + 4, c);
+            if ((threadIdx.x & 63u) == 0) st32u(rec + 4 + c, x);
+            len += 4;
+        }
+        if ((threadIdx.x & 63u) == 0) { st32u(rec, word); a.result[i] = len; }
+    }
+}
+
+// Raw LZ4 blocks with a dictionary context (StreamIndieCtx): the block API with WithBlockDictionary (plz4_block.go:48-53).
+__global__ __launch_bounds__(64) void k_encode_raw_dict(CodecArgs a)
+{
+    __shared__ uint32_t lds[kHashBytes / 4];
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int n = block_len(a, i);
+        DictEnc dc{nullptr, 0, kDictNonePrefix, nullptr};
+        if (a.dictLen >= 8) { dc.dict = a.dict; dc.dictSize = a.dictLen; dc.dictTable = a.dictTable; dc.mode = n > 4096 ? kDictCtxCopy : kDictCtxLookup; }
+        const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
+        const int r = wave_encode_block_dict(a.src + (int64_t)i * a.srcStride, n, a.dst + (int64_t)i * a.dstStride, cap, dc, lds);
+        if ((threadIdx.x & 63u) == 0) a.result[i] = r;
+    }
+}
+
+// One record against an optional dictionary; shared by the independent and the linked decode kernels.
+__device__ __forceinline__ void decode_one_record(const CodecArgs& a, int i, const uint8_t* dict, int dictLen, int* rOut, int* stOut, bool* stored)
+{
+    const uint8_t* rec    = a.recOff ? a.src + a.recOff[i] : a.src + (int64_t)i * a.srcStride;
+    const int64_t  recLen = a.recOff ? a.recOff[i + 1] - a.recOff[i] : (int64_t)a.srcLen[i];
+    uint8_t*       out    = a.dst + (int64_t)i * a.dstStride;
+    const uint32_t word   = plz4_readfirstlane(ld32u(rec));
+    const int      sz     = (int)(word & 0x7FFFFFFFu);
+    int st = PLZ4HIP_BLK_OK, r = 0;
+    *stored = false;
+    if (sz > a.bsz || (int64_t)sz + 4 + (a.blockChecksum ? 4 : 0) > recLen) {
+        st = PLZ4HIP_BLK_SIZE_OVERFLOW;
+    } else {
+        if (a.blockChecksum) {
+            const uint32_t want = plz4_readfirstlane(ld32u(rec + 4 + sz));
+            if (wave_xxh32(rec + 4, sz) != want) st = PLZ4HIP_BLK_HASH_MISMATCH;
+        }
+        if (st == PLZ4HIP_BLK_OK) {
+            if (word & 0x80000000u) {
+                if (sz > a.dstCapAll) st = PLZ4HIP_BLK_SIZE_OVERFLOW;
+                else { wave_copy(out, rec + 4, sz); r = sz; *stored = true; }
+            } else {
+                r = wave_decode_block(rec + 4, sz, out, a.dstCapAll, dict, dictLen);
+                if (r < 0) st = PLZ4HIP_BLK_CORRUPT;
+            }
+        }
+    }
+    *rOut = r; *stOut = st;
+}
+
+// Independent blocks with a dictionary (indieDecompressorWithDict, compress/decompress.go:42-58, linked == false).
+__global__ __launch_bounds__(64) void k_decode_rec_dict(CodecArgs a)
+{
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        int r, st; bool stored;
+        decode_one_record(a, i, a.dict, a.dictLen, &r, &st, &stored);
+        if ((threadIdx.x & 63u) == 0) { a.result[i] = r; a.status[i] = st; }
+    }
+}
+
+// Linked blocks: a serial chain, one wave.  The window follows compress.DictT.Update (compress/dict.go:28-41) and is
+// NOT updated by stored blocks (sync/reader.go:75-78, async/reader.go:149-163) -- the reference's behaviour, kept.
+__global__ __launch_bounds__(64) void k_decode_rec_linked(CodecArgs a)
+{
+    uint8_t* winA = a.window; uint8_t* winB = a.window + 65536;
+    int winLen = *a.windowLen;
+    bool dead = false;
+    for (int i = 0; i < a.nBlocks; ++i) {
+        int r = 0, st = PLZ4HIP_BLK_CORRUPT; bool stored = false;
+        if (!dead) decode_one_record(a, i, winA, winLen, &r, &st, &stored);
+        if ((threadIdx.x & 63u) == 0) { a.result[i] = r; a.status[i] = st; }
+        if (st != PLZ4HIP_BLK_OK) { dead = true; continue; }             // first error ends the stream
+        if (stored) continue;
+        const uint8_t* out = a.dst + (int64_t)i * a.dstStride;
+        WAVE_FENCE();
+        if (r >= 65536) { wave_copy(winB, out + (r - 65536), 65536); winLen = 65536; }
+        else {
+            int keep = winLen;
+            if (winLen + r > 65536) keep = 65536 - r;
+            wave_copy(winB, winA + (winLen - keep), keep);
+            wave_copy(winB + keep, out, r);
+            winLen = keep + r;
+        }
+        WAVE_FENCE();
+        uint8_t* t = winA; winA = winB; winB = t;
+    }
+    // leave the live window in the first half for the next call
+    if (winA != a.window) { WAVE_FENCE(); wave_copy(a.window, winA, winLen); }
+    if ((threadIdx.x & 63u) == 0) *a.windowLen = winLen;
+}
+
+__global__ __launch_bounds__(64) void k_decode_raw_dict(CodecArgs a)
+{
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
+        const int r = wave_decode_block(a.src + (int64_t)i * a.srcStride, a.srcLen[i], a.dst + (int64_t)i * a.dstStride, cap, a.dict, a.dictLen);
+        if ((threadIdx.x & 63u) == 0) a.result[i] = r;
     }
 }
 
@@ -196,9 +332,28 @@ struct plz4hip_ctx {
     uint8_t*     d_buf = nullptr;  size_t d_cap = 0;
 };
 
+// == clz4.DictCtx (clz4.go:96-120): a private device copy of the last 64 KiB of the dictionary + the LZ4_loadDictSlow table.
+struct plz4hip_dict {
+    uint8_t*  d_bytes = nullptr;  int len = 0;      // len < 8: the dictionary is dropped by liblz4 (lz4.c:1613-1615)
+    uint32_t* d_table = nullptr;
+    std::vector<uint8_t> h_bytes;
+};
+
 namespace {
 
 constexpr int kQueueSlots = 256;
+
+// LZ4_loadDict_internal(_ld_slow) on the host (lz4.c:1587-1646): the table a dictionary context carries.
+void build_dict_table_slow(const uint8_t* p, int n, uint32_t* tab)
+{
+    memset(tab, 0, 4096 * sizeof(uint32_t));
+    if (n < 8) return;
+    auto hash5 = [](const uint8_t* q) { uint64_t v; memcpy(&v, q, 8); return (uint32_t)(((v << 24) * 889523592379ull) >> 52); };
+    const uint32_t cur = 65536, base = cur - (uint32_t)n;
+    for (int i = 0; i <= n - 8; i += 3) tab[hash5(p + i)] = base + (uint32_t)i;                 // later entries overwrite
+    const uint32_t limit = cur - 65536;
+    for (int i = 0; i <= n - 8; i++) { const uint32_t h = hash5(p + i); if (tab[h] <= limit) tab[h] = base + (uint32_t)i; }
+}
 
 int fail(plz4hip_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
 {
@@ -452,9 +607,17 @@ Staging plan(int n, int maxIn, int maxOut)
 }
 }  // namespace
 
+struct DictJob {                       // optional dictionary / linked parameters of a host call
+    const plz4hip_dict* dict = nullptr;
+    int   linked = 0;
+    const void* prevTail = nullptr; int prevTailLen = -1;
+    uint8_t* window = nullptr; int* windowLen = nullptr;      // host buffers (64 KiB) for the linked decode chain
+    bool  any = false;
+};
+
 static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3 dec rec,4 xxh*/, int nBlocks,
                       const void* const* src, const int32_t* srcLen, void* const* dst, const int32_t* dstCap,
-                      int bsz, int blockChecksum, int32_t* result, int32_t* status)
+                      int bsz, int blockChecksum, int32_t* result, int32_t* status, const DictJob* dj = nullptr)
 {
     if (nBlocks == 0) return PLZ4HIP_OK;
     int maxIn = 0, maxOut = 0;
@@ -467,7 +630,9 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     }
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    const Staging st = plan(nBlocks, maxIn, maxOut);
+    Staging st = plan(nBlocks, maxIn, maxOut);
+    const size_t offExtra = st.total;                          // [prevTail 64 KiB][window 2 x 64 KiB][windowLen]
+    if (dj && dj->any) st.total += 3 * 65536 + 256;
     if (int rc = ensure_staging(c, st.total, st.total)) return rc;
     hipStream_t s = c->stream;
     int32_t* hA = (int32_t*)(c->h_pin + st.offA);
@@ -484,11 +649,36 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     a.dst = c->d_buf + st.offOut; a.dstStride = st.outStride; a.dstCap = (const int32_t*)(c->d_buf + st.offB);
     a.result = (int32_t*)(c->d_buf + st.offRes); a.status = (int32_t*)(c->d_buf + st.offSt);
     a.queue = q; a.nBlocks = nBlocks; a.bsz = bsz; a.blockChecksum = blockChecksum; a.dstCapAll = bsz + 8;
+    const bool dictMode = dj && dj->any;
+    a.dictLen = -1; a.prevTailLen = -1;
+    if (dictMode) {
+        if (dj->dict) { a.dict = dj->dict->d_bytes; a.dictLen = dj->dict->len; a.dictTable = dj->dict->d_table; }
+        a.linked = dj->linked;
+        if (dj->prevTail && dj->prevTailLen >= 0) {
+            if (dj->prevTailLen > 65536) return fail(c, PLZ4HIP_E_ARG, "prevTail longer than 64 KiB");
+            memcpy(c->h_pin + offExtra, dj->prevTail, (size_t)dj->prevTailLen);
+            HIPCHK(c, hipMemcpyAsync(c->d_buf + offExtra, c->h_pin + offExtra, (size_t)dj->prevTailLen + 16, hipMemcpyHostToDevice, s));
+            a.prevTail = c->d_buf + offExtra; a.prevTailLen = dj->prevTailLen;
+        }
+        if (dj->window) {
+            memcpy(c->h_pin + offExtra + 65536, dj->window, 65536);
+            memcpy(c->h_pin + offExtra + 3 * 65536, dj->windowLen, sizeof(int));
+            HIPCHK(c, hipMemcpyAsync(c->d_buf + offExtra + 65536, c->h_pin + offExtra + 65536, 2 * 65536 + 256, hipMemcpyHostToDevice, s));
+            a.window = c->d_buf + offExtra + 65536; a.windowLen = (int*)(c->d_buf + offExtra + 3 * 65536);
+        }
+    }
     switch (mode) {
-    case 0: hipLaunchKernelGGL(k_encode_raw, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
-    case 1: hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a); break;
-    case 2: a.dstCap = nullptr; hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
-    case 3: a.dstCap = nullptr; hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a); break;
+    case 0: if (dictMode) hipLaunchKernelGGL(k_encode_raw_dict, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL(k_encode_raw, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
+    case 1: if (dictMode) hipLaunchKernelGGL(k_decode_raw_dict, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a); break;
+    case 2: a.dstCap = nullptr;
+            if (dictMode) hipLaunchKernelGGL(k_encode_rec_dict, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
+    case 3: a.dstCap = nullptr;
+            if (dictMode && dj->linked) hipLaunchKernelGGL(k_decode_rec_linked, dim3(1), dim3(64), 0, s, a);
+            else if (dictMode) hipLaunchKernelGGL(k_decode_rec_dict, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
+            else hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a); break;
     case 4: hipLaunchKernelGGL(k_xxh32, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s,
                                (const uint8_t*)a.src, a.srcStride, a.srcLen, (uint32_t*)a.result, nBlocks, q); break;
     }
@@ -498,7 +688,13 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     HIPCHK(c, hipMemcpyAsync(c->h_pin + st.offRes, c->d_buf + st.offRes, 2 * (st.offSt - st.offRes), hipMemcpyDeviceToHost, s));
     if (mode != 4)
         HIPCHK(c, hipMemcpyAsync(c->h_pin + st.offOut, c->d_buf + st.offOut, (size_t)nBlocks * st.outStride, hipMemcpyDeviceToHost, s));
+    if (dictMode && dj->window)
+        HIPCHK(c, hipMemcpyAsync(c->h_pin + offExtra + 65536, c->d_buf + offExtra + 65536, 2 * 65536 + 256, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
+    if (dictMode && dj->window) {
+        memcpy(dj->window, c->h_pin + offExtra + 65536, 65536);
+        memcpy(dj->windowLen, c->h_pin + offExtra + 3 * 65536, sizeof(int));
+    }
     const int32_t* hRes = (const int32_t*)(c->h_pin + st.offRes);
     const int32_t* hSt  = (const int32_t*)(c->h_pin + st.offSt);
     for (int i = 0; i < nBlocks; ++i) {
@@ -545,6 +741,80 @@ int plz4hip_decode_records(plz4hip_ctx* c, int nBlocks, const void* const* rec, 
     if (!c || nBlocks < 0 || bsz <= 0 || (nBlocks && (!rec || !recLen || !dst || !result || !status))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_decode_records: bad argument");
     for (int i = 0; i < nBlocks; ++i) if (recLen[i] < 4) return fail(c, PLZ4HIP_E_ARG, "record shorter than its size word");
     return host_codec(c, 3, nBlocks, rec, recLen, dst, nullptr, bsz, blockChecksum, result, status);
+}
+
+// ---------------------------------------------------------------------------------------- dictionaries / linked blocks
+int plz4hip_dict_create(plz4hip_ctx* c, const void* dict, int dictLen, plz4hip_dict** out)
+{
+    if (!c || !out || dictLen < 0 || (dictLen && !dict)) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dict_create: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    plz4hip_dict* d = new (std::nothrow) plz4hip_dict();
+    if (!d) return fail(c, PLZ4HIP_E_NOMEM, "plz4hip_dict");
+    const uint8_t* p = (const uint8_t*)dict;
+    if (dictLen > 65536) { p += dictLen - 65536; dictLen = 65536; }             // compress/dict.go:43-56, lz4.c:1617
+    d->h_bytes.assign(p, p + dictLen);
+    d->len = dictLen;
+    std::vector<uint32_t> tab(4096);
+    build_dict_table_slow(d->h_bytes.data(), dictLen, tab.data());
+    hipError_t e = hipMalloc((void**)&d->d_bytes, 65536 + 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&d->d_table, 4096 * sizeof(uint32_t));
+    if (e == hipSuccess && dictLen) e = hipMemcpy(d->d_bytes, d->h_bytes.data(), (size_t)dictLen, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d->d_table, tab.data(), 4096 * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { if (d->d_bytes) hipFree(d->d_bytes); if (d->d_table) hipFree(d->d_table); delete d; return fail(c, PLZ4HIP_E_DEVICE, "plz4hip_dict_create", e); }
+    *out = d;
+    return PLZ4HIP_OK;
+}
+
+void plz4hip_dict_destroy(plz4hip_ctx* c, plz4hip_dict* d)
+{
+    if (!d) return;
+    if (c) hipSetDevice(c->device);
+    if (d->d_bytes) hipFree(d->d_bytes);
+    if (d->d_table) hipFree(d->d_table);
+    delete d;
+}
+
+int plz4hip_compress_batch_dict(plz4hip_ctx* c, int nBlocks, const void* const* src, const int32_t* srcLen,
+                                void* const* dst, const int32_t* dstCap, int level, const plz4hip_dict* dict, int32_t* result)
+{
+    if (!c || !dict || nBlocks < 0 || (nBlocks && (!src || !srcLen || !dst || !dstCap || !result))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_compress_batch_dict: bad argument");
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    DictJob j; j.dict = dict; j.any = true;
+    return host_codec(c, 0, nBlocks, src, srcLen, dst, dstCap, 0, 0, result, nullptr, &j);
+}
+
+int plz4hip_decompress_batch_dict(plz4hip_ctx* c, int nBlocks, const void* const* src, const int32_t* srcLen,
+                                  void* const* dst, const int32_t* dstCap, const plz4hip_dict* dict, int32_t* result)
+{
+    if (!c || !dict || nBlocks < 0 || (nBlocks && (!src || !srcLen || !dst || !dstCap || !result))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_decompress_batch_dict: bad argument");
+    DictJob j; j.dict = dict; j.any = true;
+    return host_codec(c, 1, nBlocks, src, srcLen, dst, dstCap, 0, 0, result, nullptr, &j);
+}
+
+int plz4hip_encode_records_ex(plz4hip_ctx* c, int nBlocks, const void* const* src, const int32_t* srcLen,
+                              int bsz, int level, int blockChecksum, int linked, const plz4hip_dict* dict,
+                              const void* prevTail, int prevTailLen, void* const* rec, int32_t* recLen)
+{
+    if (!c || nBlocks < 0 || bsz <= 0 || (nBlocks && (!src || !srcLen || !rec || !recLen))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_encode_records_ex: bad argument");
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    for (int i = 0; i < nBlocks; ++i) if (srcLen[i] > bsz) return fail(c, PLZ4HIP_E_ARG, "source block larger than block size");
+    if (!linked && !dict) return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr);
+    DictJob j; j.dict = dict; j.linked = linked; j.prevTail = prevTail; j.prevTailLen = (linked && prevTail) ? prevTailLen : -1; j.any = true;
+    return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr, &j);
+}
+
+int plz4hip_decode_records_ex(plz4hip_ctx* c, int nBlocks, const void* const* rec, const int32_t* recLen,
+                              int bsz, int blockChecksum, int linked, const plz4hip_dict* dict,
+                              void* window, int* windowLen, void* const* dst, int32_t* result, int32_t* status)
+{
+    if (!c || nBlocks < 0 || bsz <= 0 || (nBlocks && (!rec || !recLen || !dst || !result || !status))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_decode_records_ex: bad argument");
+    for (int i = 0; i < nBlocks; ++i) if (recLen[i] < 4) return fail(c, PLZ4HIP_E_ARG, "record shorter than its size word");
+    if (!linked && !dict) return host_codec(c, 3, nBlocks, rec, recLen, dst, nullptr, bsz, blockChecksum, result, status);
+    if (linked && (!window || !windowLen || *windowLen < 0 || *windowLen > 65536)) return fail(c, PLZ4HIP_E_ARG, "linked decode needs the 64 KiB window state");
+    DictJob j; j.dict = dict; j.linked = linked; j.any = true;
+    if (linked) { j.window = (uint8_t*)window; j.windowLen = windowLen; j.dict = nullptr; }
+    return host_codec(c, 3, nBlocks, rec, recLen, dst, nullptr, bsz, blockChecksum, result, status, &j);
 }
 
 }  // extern "C"

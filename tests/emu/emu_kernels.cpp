@@ -24,4 +24,17 @@ int emu_decode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
 
 uint32_t emu_xxh32(const uint8_t* p, int n) { return plz4::wave_xxh32(p, n); }
 
+int emu_encode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, const uint8_t* dict, int dictSize, int mode,
+                          const uint32_t* dictTable)
+{
+    static thread_local uint32_t lds[plz4::kHashBytes / 4];
+    plz4::DictEnc dc{dict, dictSize, mode, dictTable};
+    return plz4::wave_encode_block_dict(src, n, dst, cap, dc, lds);
+}
+
+int emu_decode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, const uint8_t* dict, int dictSize)
+{
+    return plz4::wave_decode_block(src, n, dst, cap, dict, dictSize);
+}
+
 }

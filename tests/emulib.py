@@ -34,6 +34,24 @@ class Emu:
         L.emu_xxh32.restype = C.c_uint32
         L.emu_xxh32.argtypes = [u8p, C.c_int]
 
+        L.emu_encode_block_dict.restype = C.c_int
+        L.emu_encode_block_dict.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_void_p]
+        L.emu_decode_block_dict.restype = C.c_int
+        L.emu_decode_block_dict.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.c_int]
+
+    def compress_dict(self, src, cap, dct, mode, table=None):
+        dst = np.empty(max(cap, 1) + 32, dtype=np.uint8)
+        tp = table.ctypes.data if table is not None else None
+        r = int(self.L.emu_encode_block_dict(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap,
+                                             _ptr(dct) if dct is not None and dct.size else C.cast(None, u8p),
+                                             0 if dct is None else dct.size, mode, tp))
+        return r, dst[:max(r, 0)]
+
+    def decompress_dict(self, src, cap, dct):
+        dst = np.zeros(max(cap, 1) + 32, dtype=np.uint8)
+        r = int(self.L.emu_decode_block_dict(_ptr(src), src.size, _ptr(dst), cap, _ptr(dct), dct.size))
+        return r, dst[:max(r, 0)]
+
     def set_descending(self, d: bool):
         self.L.emu_set_descending(int(d))
 

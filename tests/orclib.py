@@ -97,6 +97,34 @@ class Oracle:
         r = int(self.L.orc_decompress_safe_dict(_ptr(src), src.size, _ptr(dst), cap, _ptr(dct), dct.size))
         return r, dst[:max(r, 0)]
 
+    # ---- streams (config 5): the three ways plz4 primes a level-1 stream (clz4.go:96-120, :160-179, :224-248)
+    def dict_ctx(self, dct: np.ndarray) -> "OrcStream":
+        """clz4.NewDictCtx: resetStream_fast + LZ4_loadDictSlow."""
+        d = OrcStream(); self.L.orc_stream_init(C.byref(d)); self.L.orc_stream_reset_fast(C.byref(d))
+        self._keep = getattr(self, "_keep", []); self._keep.append(dct)
+        self.L.orc_stream_load_dict(C.byref(d), _ptr(dct) if dct.size else C.cast(None, u8p), dct.size, 1)
+        return d
+
+    def compress_indie_dict(self, src: np.ndarray, cap: int, dctx: "OrcStream"):
+        """StreamIndieCtx.Compress: resetStream_fast + attach_dictionary + compress_fast_continue on a fresh stream."""
+        s = OrcStream(); self.L.orc_stream_init(C.byref(s)); self.L.orc_stream_reset_fast(C.byref(s))
+        self.L.orc_stream_attach(C.byref(s), C.byref(dctx))
+        dst = np.empty(max(cap, 1), dtype=np.uint8)
+        r = int(self.L.orc_stream_compress(C.byref(s), _ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap))
+        return r, dst[:max(r, 0)]
+
+    def compress_linked(self, src: np.ndarray, cap: int, prev_tail, dctx=None):
+        """StreamLinkedCtx.Compress for one block: block 0 (prev_tail None) runs on the fresh stream (+ attached dict ctx),
+        later blocks LZ4_loadDict(prev_tail) first.  Equivalent to the worker-owned stream because loadDict resets it."""
+        s = OrcStream(); self.L.orc_stream_init(C.byref(s)); self.L.orc_stream_reset_fast(C.byref(s))
+        if dctx is not None:
+            self.L.orc_stream_attach(C.byref(s), C.byref(dctx))
+        if prev_tail is not None:
+            self.L.orc_stream_load_dict(C.byref(s), _ptr(prev_tail) if prev_tail.size else C.cast(None, u8p), prev_tail.size, 0)
+        dst = np.empty(max(cap, 1), dtype=np.uint8)
+        r = int(self.L.orc_stream_compress(C.byref(s), _ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap))
+        return r, dst[:max(r, 0)]
+
     def block_record(self, src: np.ndarray, bsz: int, block_checksum: bool):
         rec = np.empty(bsz + 8, dtype=np.uint8)
         r = int(self.L.orc_block_record(_ptr(src), src.size, bsz, int(block_checksum), _ptr(rec)))

@@ -140,3 +140,71 @@ def test_emu_xxh32(orc, emu):
     for n in list(range(0, 70)) + [127, 128, 129, 255, 1000, 4096, 100003, 1 << 20]:
         a = rng.integers(0, 256, size=n, dtype=np.uint8)
         assert emu.xxh32(a) == orc.xxh32(a), n
+
+
+# ------------------------------------------------------------------------------------------------ config 5: dictionary / linked modes
+def _dict_table(dctx):
+    return np.ctypeslib.as_array(dctx.table).astype(np.uint32).copy()
+
+
+def test_emu_encode_indie_with_dictionary(orc, emu):
+    """StreamIndieCtx (clz4.go:160-179): > 4 KiB copies the dictionary context's table (mode 2), <= 4 KiB looks it up (mode 3)."""
+    dct_full = synth.text(70000, seed=99)
+    data = synth.text(300000, seed=7)
+    for dct_user in (dct_full, dct_full[:30000], dct_full[:100], dct_full[:5]):
+        dctx = orc.dict_ctx(dct_user)
+        dct = np.ascontiguousarray(dct_user[-65536:])
+        tab = _dict_table(dctx)
+        for n in (0, 5, 12, 13, 100, 4095, 4096, 4097, 65536, 200000):
+            src = np.ascontiguousarray(data[:n])
+            for cap in (max(n, 1), n + n // 255 + 16):
+                a, da = orc.compress_indie_dict(src, cap, dctx)
+                mode = 4 if dct.size < 8 else (2 if n > 4096 else 3)
+                b, db = emu.compress_dict(src, cap, dct if mode != 4 else None, mode, tab)
+                assert a == b and np.array_equal(da, db), (dct.size, n, cap, a, b)
+
+
+def test_emu_encode_linked(orc, emu):
+    """StreamLinkedCtx (clz4.go:224-248): block 0 fresh (mode 0), later blocks LZ4_loadDict(previous tail) (mode 1, or 4 if < 8 bytes)."""
+    data = synth.make("M", 5 * 65536 + 777, 65536, seed=3)
+    for bsz in (65536, 100000):
+        prev = None
+        for off in range(0, data.size, bsz):
+            src = np.ascontiguousarray(data[off:off + bsz]); n = src.size
+            tail = None if prev is None else prev[-65536:].copy()      # a separate buffer, like the pooled dict block (async/writer.go:412-437)
+            a, da = orc.compress_linked(src, n, tail)
+            mode = 0 if tail is None else (1 if tail.size >= 8 else 4)
+            b, db = emu.compress_dict(src, n, tail if mode == 1 else None, mode)
+            assert a == b and np.array_equal(da, db), (bsz, off, a, b)
+            prev = src
+    # tiny previous block (flush of a few bytes): LZ4_loadDict drops it (lz4.c:1613-1615)
+    src = np.ascontiguousarray(data[:5000]); tail = data[5000:5005].copy()
+    a, da = orc.compress_linked(src, 5000, tail)
+    b, db = emu.compress_dict(src, 5000, None, 4)
+    assert a == b and np.array_equal(da, db)
+
+
+def test_emu_decode_with_dictionary(orc, emu):
+    dct_user = synth.text(70000, seed=99)
+    dct = np.ascontiguousarray(dct_user[-65536:])
+    dctx = orc.dict_ctx(dct_user)
+    data = synth.text(200000, seed=7)
+    rng = np.random.default_rng(4)
+    for n in (100, 4096, 5000, 65536, 200000):
+        src = np.ascontiguousarray(data[:n])
+        c, comp = orc.compress_indie_dict(src, n + n // 255 + 16, dctx)
+        comp = np.ascontiguousarray(comp)
+        for d in (dct, np.ascontiguousarray(dct[-1000:])):          # full window and a short one (checkOffset on)
+            for cap in (n, n + 8, n - 1):
+                a, da = orc.decompress_safe_dict(comp, cap, d)
+                b, db = emu.decompress_dict(comp, cap, d)
+                assert a == b, (n, d.size, cap, a, b)
+                if a >= 0:
+                    assert np.array_equal(da, db)
+        for t in range(20):
+            bad = comp.copy(); bad[int(rng.integers(0, bad.size))] ^= 1 << int(rng.integers(0, 8))
+            a, da = orc.decompress_safe_dict(bad, n + 8, dct)
+            b, db = emu.decompress_dict(bad, n + 8, dct)
+            assert a == b
+            if a >= 0:
+                assert np.array_equal(da, db)
