@@ -20,6 +20,8 @@ typedef struct plz4h_opts {
     int32_t  fail_after_writes;      // sink: the N-th Write (0-based) and all later ones fail; -1 = never
     int64_t  fail_read_at;           // source: reads fail once this many bytes were delivered; -1 = never
     int32_t  has_dictionary;
+    const uint8_t* dictionary;       // WithDictionary bytes (has_dictionary != 0)
+    int64_t  dictionary_len;
 } plz4h_opts;
 
 }  // extern "C"
@@ -38,6 +40,7 @@ Options to_options(const plz4h_opts* o, std::vector<int64_t>* prog)
     x.HasDictionaryId = o->has_dict_id != 0; x.DictionaryId = o->dict_id;
     x.BlockSizeIdx = (o->block_size_idx >= 4 && o->block_size_idx <= 7) ? o->block_size_idx : BlockIdx4MB;   // WithBlockSize
     x.GpuBatchBlocks = o->gpu_batch; x.HasDictionary = o->has_dictionary != 0;
+    if (x.HasDictionary && o->dictionary && o->dictionary_len > 0) x.Dictionary.assign(o->dictionary, o->dictionary + o->dictionary_len);
     if (x.Level < 1) x.Level = 1; if (x.Level > 12) x.Level = 12;                                               // WithLevel
     if (prog) x.Handler = [prog](int64_t a, int64_t b) { prog->push_back(a); prog->push_back(b); };
     return x;
@@ -115,17 +118,21 @@ int    plz4h_reader_close(void* r) { return enc(((ReaderH*)r)->r->Close()); }
 void   plz4h_reader_free(void* r) { delete (ReaderH*)r; }
 
 int plz4h_compress_block_bound(int n) { return CompressBlockBound(n); }
-int plz4h_compress_block(void* engine, const uint8_t* src, size_t n, int level, uint8_t* dst, size_t cap, int dst_provided, size_t* out_len)
+int plz4h_compress_block(void* engine, const uint8_t* src, size_t n, int level, uint8_t* dst, size_t cap, int dst_provided, size_t* out_len,
+                         const uint8_t* dict, int64_t dict_len)
 {
     std::vector<uint8_t> d; if (dst_provided) d.assign(cap, 0);
-    Error e = CompressBlock(*(BlockEngine*)engine, src, n, level, &d, dst_provided != 0);
+    std::vector<uint8_t> dv; if (dict_len >= 0) dv.assign(dict, dict + dict_len);
+    Error e = CompressBlock(*(BlockEngine*)engine, src, n, level, &d, dst_provided != 0, dict_len >= 0 ? &dv : nullptr);
     if (!e) { if (d.size() > cap) return enc(Error{ErrCompress, false}); memcpy(dst, d.data(), d.size()); *out_len = d.size(); }
     return enc(e);
 }
-int plz4h_decompress_block(void* engine, const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int dst_provided, size_t* out_len)
+int plz4h_decompress_block(void* engine, const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int dst_provided, size_t* out_len,
+                           const uint8_t* dict, int64_t dict_len)
 {
     std::vector<uint8_t> d; if (dst_provided) d.assign(cap, 0);
-    Error e = DecompressBlock(*(BlockEngine*)engine, src, n, &d, dst_provided != 0);
+    std::vector<uint8_t> dv; if (dict_len >= 0) dv.assign(dict, dict + dict_len);
+    Error e = DecompressBlock(*(BlockEngine*)engine, src, n, &d, dst_provided != 0, dict_len >= 0 ? &dv : nullptr);
     if (!e) { if (d.size() > cap) return enc(Error{ErrDecompress, true}); memcpy(dst, d.data(), d.size()); *out_len = d.size(); }
     return enc(e);
 }

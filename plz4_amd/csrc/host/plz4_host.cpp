@@ -117,6 +117,18 @@ struct HipEngine : BlockEngine {
     { return plz4hip_encode_records(ctx, n, s, sl, bsz, lvl, bc, rec, rl_); }
     int DecodeRecords(int n, const void* const* rec, const int32_t* rl_, int bsz, int bc, void* const* d, int32_t* r, int32_t* st) override
     { return plz4hip_decode_records(ctx, n, rec, rl_, bsz, bc, d, r, st); }
+    void* DictCreate(const uint8_t* p, int n) override { plz4hip_dict* d = nullptr; return plz4hip_dict_create(ctx, p, n, &d) == 0 ? d : nullptr; }
+    void  DictDestroy(void* d) override { plz4hip_dict_destroy(ctx, (plz4hip_dict*)d); }
+    int CompressBatchDict(int n, const void* const* s, const int32_t* sl, void* const* d, const int32_t* dc, int lvl, void* dict, int32_t* r) override
+    { return plz4hip_compress_batch_dict(ctx, n, s, sl, d, dc, lvl, (plz4hip_dict*)dict, r); }
+    int DecompressBatchDict(int n, const void* const* s, const int32_t* sl, void* const* d, const int32_t* dc, void* dict, int32_t* r) override
+    { return plz4hip_decompress_batch_dict(ctx, n, s, sl, d, dc, (plz4hip_dict*)dict, r); }
+    int EncodeRecordsEx(int n, const void* const* s, const int32_t* sl, int bsz, int lvl, int bc, int linked, void* dict,
+                        const void* pt, int ptl, void* const* rec, int32_t* rl_) override
+    { return plz4hip_encode_records_ex(ctx, n, s, sl, bsz, lvl, bc, linked, (plz4hip_dict*)dict, pt, ptl, rec, rl_); }
+    int DecodeRecordsEx(int n, const void* const* rec, const int32_t* rl_, int bsz, int bc, int linked, void* dict, void* win, int* wl,
+                        void* const* d, int32_t* r, int32_t* st) override
+    { return plz4hip_decode_records_ex(ctx, n, rec, rl_, bsz, bc, linked, (plz4hip_dict*)dict, win, wl, d, r, st); }
 };
 struct VtEngine : BlockEngine {
     EngineVTable vt;
@@ -128,6 +140,18 @@ struct VtEngine : BlockEngine {
     { return vt.encode_records(vt.user, n, s, sl, bsz, lvl, bc, rec, rl_); }
     int DecodeRecords(int n, const void* const* rec, const int32_t* rl_, int bsz, int bc, void* const* d, int32_t* r, int32_t* st) override
     { return vt.decode_records(vt.user, n, rec, rl_, bsz, bc, d, r, st); }
+    void* DictCreate(const uint8_t* p, int n) override { return vt.dict_create ? vt.dict_create(vt.user, p, n) : nullptr; }
+    void  DictDestroy(void* d) override { if (vt.dict_destroy) vt.dict_destroy(vt.user, d); }
+    int CompressBatchDict(int n, const void* const* s, const int32_t* sl, void* const* d, const int32_t* dc, int lvl, void* dict, int32_t* r) override
+    { return vt.compress_batch_dict ? vt.compress_batch_dict(vt.user, n, s, sl, d, dc, lvl, dict, r) : -4; }
+    int DecompressBatchDict(int n, const void* const* s, const int32_t* sl, void* const* d, const int32_t* dc, void* dict, int32_t* r) override
+    { return vt.decompress_batch_dict ? vt.decompress_batch_dict(vt.user, n, s, sl, d, dc, dict, r) : -4; }
+    int EncodeRecordsEx(int n, const void* const* s, const int32_t* sl, int bsz, int lvl, int bc, int linked, void* dict,
+                        const void* pt, int ptl, void* const* rec, int32_t* rl_) override
+    { return vt.encode_records_ex ? vt.encode_records_ex(vt.user, n, s, sl, bsz, lvl, bc, linked, dict, pt, ptl, rec, rl_) : -4; }
+    int DecodeRecordsEx(int n, const void* const* rec, const int32_t* rl_, int bsz, int bc, int linked, void* dict, void* win, int* wl,
+                        void* const* d, int32_t* r, int32_t* st) override
+    { return vt.decode_records_ex ? vt.decode_records_ex(vt.user, n, rec, rl_, bsz, bc, linked, dict, win, wl, d, r, st) : -4; }
 };
 }  // namespace
 std::unique_ptr<BlockEngine> NewHipEngine(int device, int* rc)
@@ -152,7 +176,26 @@ class WriterImpl : public Writer {
     Error state;                                            // first error wins (async/writer.go:552-555)
     int64_t srcMark = 0, dstMark = 0;
     Xxh32Stream hasher; bool hashing;
+    void* dictH = nullptr; bool dictTried = false;          // compress.NewCompressorFactory(level, independent, dict)
+    std::vector<uint8_t> lastTail; bool haveTail = false;   // linked: last <= 64 KiB of the previous block (async/writer.go:412-437)
     void progress(int64_t a, int64_t b) { if (o.Handler) o.Handler(a, b); }
+    bool exMode() const { return o.BlockLinked || o.HasDictionary; }
+    Error encode(int n, const void* const* src, const int32_t* len, void* const* rec, int32_t* rlen)
+    {
+        int rc;
+        if (!exMode()) rc = eng.EncodeRecords(n, src, len, bsz, o.Level, o.BlockChecksum ? 1 : 0, rec, rlen);
+        else {
+            if (o.HasDictionary && !dictTried) { dictTried = true; dictH = eng.DictCreate(o.Dictionary.data(), (int)o.Dictionary.size()); if (!dictH) return E(ErrUnsupported); }
+            rc = eng.EncodeRecordsEx(n, src, len, bsz, o.Level, o.BlockChecksum ? 1 : 0, o.BlockLinked ? 1 : 0, dictH,
+                                     haveTail ? (const void*)lastTail.data() : nullptr, haveTail ? (int)lastTail.size() : -1, rec, rlen);
+            if (o.BlockLinked && n > 0) {
+                const uint8_t* lp = (const uint8_t*)src[n - 1]; const int ll = len[n - 1]; const int k = ll < 65536 ? ll : 65536;
+                lastTail.assign(lp + (ll - k), lp + ll); haveTail = true;
+            }
+        }
+        if (rc != 0) return E(rc == PLZ4HIP_E_UNSUPPORTED ? ErrUnsupported : ErrEngine);
+        return Error();
+    }
     Error sinkWrite(const uint8_t* p, size_t n, size_t* w) { size_t ww = 0; Error e = wr.write(p, n, &ww); if (w) *w = ww; return e; }
     Error writeHeader()
     {
@@ -165,7 +208,7 @@ class WriterImpl : public Writer {
     }
     Error supported() const
     {
-        if (o.Level != 1 || o.BlockLinked || o.HasDictionary) return E(ErrUnsupported);
+        if (o.Level != 1) return E(ErrUnsupported);          // HC levels: next round
         return Error();
     }
     // blk.CompressToBlk x n on the engine, then in-order emission (async/writer.go:284-381 writeLoop)
@@ -178,8 +221,7 @@ class WriterImpl : public Writer {
         std::vector<const void*> src(n); std::vector<int32_t> len(n), rlen(n); std::vector<void*> rec(n);
         std::vector<std::vector<uint8_t>> recs(n);
         for (int i = 0; i < n; i++) { src[i] = queue[i].data(); len[i] = (int32_t)queue[i].size(); recs[i].resize((size_t)bsz + 8); rec[i] = recs[i].data(); }
-        const int rc = eng.EncodeRecords(n, src.data(), len.data(), bsz, o.Level, o.BlockChecksum ? 1 : 0, rec.data(), rlen.data());
-        if (rc != 0) { queue.clear(); return E(rc == PLZ4HIP_E_UNSUPPORTED ? ErrUnsupported : ErrEngine); }
+        if (Error ee = encode(n, src.data(), len.data(), rec.data(), rlen.data())) { queue.clear(); return ee; }
         Error err;
         for (int i = 0; i < n && !err; i++) {
             size_t w = 0;
@@ -204,10 +246,11 @@ class WriterImpl : public Writer {
     }
 
 public:
+    ~WriterImpl() override { if (dictH) eng.DictDestroy(dictH); }
     WriterImpl(Sink& w, BlockEngine& e, const Options& op)
         : wr(w), eng(e), o(op), bsz(BlockIdxSize(op.BlockSizeIdx)), sync(op.NParallel == 0 && !op.BlockLinked), hashing(op.ContentChecksum)
     {
-        hasher.Reset();
+        hasher.Reset();                                      // linked => async (plz4_writer.go:44-46)
         if (!sync && o.HasContentSz && (int)(o.ContentSz / (uint64_t)bsz) + 1 > 1) kicked = true;   // async/writer.go:70-76
     }
     Error Write(const uint8_t* p, size_t n, size_t* consumed) override
@@ -286,8 +329,7 @@ public:
                 if (!e) {
                     const void* s = only.data(); int32_t l = (int32_t)only.size(), rl_ = 0;
                     std::vector<uint8_t> rec((size_t)bsz + 8); void* rp = rec.data();
-                    const int rc = eng.EncodeRecords(1, &s, &l, bsz, o.Level, o.BlockChecksum ? 1 : 0, &rp, &rl_);
-                    if (rc != 0) e = E(rc == PLZ4HIP_E_UNSUPPORTED ? ErrUnsupported : ErrEngine);
+                    e = encode(1, &s, &l, &rp, &rl_);
                     if (!e) e = sinkWrite(rec.data(), (size_t)rl_, nullptr);
                     if (!e) {
                         progress(0, hdrSz);
@@ -326,6 +368,8 @@ class ReaderImpl : public Reader {
     struct Out { std::vector<uint8_t> data; int nRead; };
     std::deque<Out> ready; Error pendingErr; int pendingRead = 0;
     std::vector<uint8_t> dstBlk; size_t dstOff = 0;
+    bool linked = false; void* dictH = nullptr; bool dictTried = false;
+    std::vector<uint8_t> window; int windowLen = 0;            // compress.DictT for linked frames
 
     void progress(int64_t a, int64_t b) { if (o.Handler) o.Handler(a, b); }
     Error readFull(uint8_t* p, size_t n, size_t* got)
@@ -386,7 +430,14 @@ class ReaderImpl : public Reader {
             o.ReadOffset = 0; clrContentChecksum = true; o.SkipContentSz = true;
         }
         if (hdr.Flags & 8) { o.HasContentSz = true; o.ContentSz = hdr.ContentSz; }
-        if (!(hdr.Flags & 0x20) || o.HasDictionary) return E(ErrUnsupported);      // linked blocks / a supplied dictionary: next round
+        linked = !(hdr.Flags & 0x20);
+        if (linked) {                                                                      // compress.NewDictT(opts.Dictionary, linked)
+            window.assign(65536, 0); windowLen = 0;
+            if (o.HasDictionary) { const size_t k = std::min<size_t>(o.Dictionary.size(), 65536); memcpy(window.data(), o.Dictionary.data() + (o.Dictionary.size() - k), k); windowLen = (int)k; }
+        } else if (o.HasDictionary && !dictTried) {
+            dictTried = true; dictH = eng.DictCreate(o.Dictionary.data(), (int)o.Dictionary.size());
+            if (!dictH) return E(ErrUnsupported);
+        }
         bsz = BlockIdxSize((hdr.BlockDesc >> 4) & 7);
         blkCheck = (hdr.Flags >> 4) & 1;
         srcCheck = ((hdr.Flags >> 2) & 1) && !clrContentChecksum;
@@ -423,8 +474,11 @@ class ReaderImpl : public Reader {
         std::vector<const void*> rp(n); std::vector<int32_t> rl_(n), res(n), st(n); std::vector<void*> dp(n);
         std::vector<std::vector<uint8_t>> outs(n);
         for (int i = 0; i < n; i++) { rp[i] = recs[i].data(); rl_[i] = (int32_t)recs[i].size(); outs[i].resize((size_t)bsz + 8); dp[i] = outs[i].data(); }
-        const int rc = eng.DecodeRecords(n, rp.data(), rl_.data(), bsz, blkCheck ? 1 : 0, dp.data(), res.data(), st.data());
-        if (rc != 0) { pendingErr = E(ErrEngine); pendingRead = 0; return; }
+        int rc;
+        if (linked) rc = eng.DecodeRecordsEx(n, rp.data(), rl_.data(), bsz, blkCheck ? 1 : 0, 1, nullptr, window.data(), &windowLen, dp.data(), res.data(), st.data());
+        else if (dictH) rc = eng.DecodeRecordsEx(n, rp.data(), rl_.data(), bsz, blkCheck ? 1 : 0, 0, dictH, nullptr, nullptr, dp.data(), res.data(), st.data());
+        else rc = eng.DecodeRecords(n, rp.data(), rl_.data(), bsz, blkCheck ? 1 : 0, dp.data(), res.data(), st.data());
+        if (rc != 0) { pendingErr = E(rc == PLZ4HIP_E_UNSUPPORTED ? ErrUnsupported : ErrEngine); pendingRead = 0; return; }
         for (int i = 0; i < n; i++) {
             if (st[i] != PLZ4HIP_BLK_OK) {
                 // the first bad block ends the stream; anything parsed after it is dropped (first error wins)
@@ -467,6 +521,7 @@ class ReaderImpl : public Reader {
 
 public:
     ReaderImpl(Source& r, BlockEngine& e, const Options& op) : rd(r), eng(e), o(op) {}
+    ~ReaderImpl() override { if (dictH) eng.DictDestroy(dictH); }
     Error Read(uint8_t* dst, size_t n, size_t* got) override
     {
         *got = 0;
@@ -535,27 +590,38 @@ std::unique_ptr<Reader> NewReader(Source& rd, BlockEngine& eng, const Options& o
 // ------------------------------------------------------------------------------------------------ block API (plz4_block.go:78-172)
 int CompressBlockBound(int sz) { return plz4hip_compress_bound(sz); }
 
-Error CompressBlock(BlockEngine& eng, const uint8_t* src, size_t n, int level, std::vector<uint8_t>* dst, bool dstProvided)
+Error CompressBlock(BlockEngine& eng, const uint8_t* src, size_t n, int level, std::vector<uint8_t>* dst, bool dstProvided,
+                    const std::vector<uint8_t>* dict)
 {
     if (level < 1) level = 1; if (level > 12) level = 12;
     if (!dstProvided) dst->assign((size_t)CompressBlockBound((int)n), 0);
     const void* s = src; int32_t sl = (int32_t)n, cap = (int32_t)dst->size(), res = 0; void* d = dst->data();
-    const int rc = eng.CompressBatch(1, &s, &sl, &d, &cap, level, &res);
+    int rc;
+    if (dict) {
+        void* dh = eng.DictCreate(dict->data(), (int)dict->size());
+        if (!dh) return E(ErrUnsupported);
+        rc = eng.CompressBatchDict(1, &s, &sl, &d, &cap, level, dh, &res);
+        eng.DictDestroy(dh);
+    } else rc = eng.CompressBatch(1, &s, &sl, &d, &cap, level, &res);
     if (rc != 0) return E(rc == PLZ4HIP_E_UNSUPPORTED ? ErrUnsupported : ErrEngine);
     if (res == 0) return E(ErrCompress);
     dst->resize((size_t)res);
     return Error();
 }
 
-Error DecompressBlock(BlockEngine& eng, const uint8_t* src, size_t n, std::vector<uint8_t>* dst, bool dstProvided)
+Error DecompressBlock(BlockEngine& eng, const uint8_t* src, size_t n, std::vector<uint8_t>* dst, bool dstProvided,
+                      const std::vector<uint8_t>* dict)
 {
     const void* s = src; int32_t sl = (int32_t)n;
+    void* dh = nullptr;
+    if (dict) { dh = eng.DictCreate(dict->data(), (int)dict->size()); if (!dh) return E(ErrUnsupported); }
+    struct Guard { BlockEngine& e; void* h; ~Guard() { if (h) e.DictDestroy(h); } } guard{eng, dh};
     size_t bufSize = dstProvided ? dst->size() : n * 4;
     for (int tries = 1;; ++tries) {
         if (!dstProvided) dst->assign(bufSize, 0);
         int32_t cap = (int32_t)dst->size(), res = 0; void* d = dst->data();
-        const int rc = eng.DecompressBatch(1, &s, &sl, &d, &cap, &res);
-        if (rc != 0) return E(ErrEngine);
+        const int rc = dh ? eng.DecompressBatchDict(1, &s, &sl, &d, &cap, dh, &res) : eng.DecompressBatch(1, &s, &sl, &d, &cap, &res);
+        if (rc != 0) return E(rc == PLZ4HIP_E_UNSUPPORTED ? ErrUnsupported : ErrEngine);
         if (res >= 0) { dst->resize((size_t)res); return Error(); }
         if (dstProvided || tries >= 3) return E(ErrDecompress, true);                      // maxTries, plz4_block.go:8-11
         bufSize *= 2;

@@ -82,6 +82,16 @@ struct BlockEngine {
                               void* const* rec, int32_t* recLen) = 0;
     virtual int DecodeRecords(int n, const void* const* rec, const int32_t* recLen, int bsz, int blockChecksum,
                               void* const* dst, int32_t* result, int32_t* status) = 0;
+    // dictionaries / linked blocks (compress.NewCompressorFactory(level, independent, dict), compress.go:32-48).
+    // Default: not supported by this engine.
+    virtual void* DictCreate(const uint8_t* /*dict*/, int /*len*/) { return nullptr; }
+    virtual void  DictDestroy(void* /*d*/) {}
+    virtual int CompressBatchDict(int, const void* const*, const int32_t*, void* const*, const int32_t*, int, void*, int32_t*) { return -4; }
+    virtual int DecompressBatchDict(int, const void* const*, const int32_t*, void* const*, const int32_t*, void*, int32_t*) { return -4; }
+    virtual int EncodeRecordsEx(int, const void* const*, const int32_t*, int, int, int, int /*linked*/, void* /*dict*/,
+                                const void* /*prevTail*/, int /*prevTailLen*/, void* const*, int32_t*) { return -4; }
+    virtual int DecodeRecordsEx(int, const void* const*, const int32_t*, int, int, int /*linked*/, void* /*dict*/,
+                                void* /*window*/, int* /*windowLen*/, void* const*, int32_t*, int32_t*) { return -4; }
 };
 std::unique_ptr<BlockEngine> NewHipEngine(int device, int* rc);     // the product engine (plz4hip_ctx)
 
@@ -92,6 +102,13 @@ struct EngineVTable {
     int (*decompress_batch)(void*, int, const void* const*, const int32_t*, void* const*, const int32_t*, int32_t*);
     int (*encode_records)(void*, int, const void* const*, const int32_t*, int, int, int, void* const*, int32_t*);
     int (*decode_records)(void*, int, const void* const*, const int32_t*, int, int, void* const*, int32_t*, int32_t*);
+    // optional (may be null): dictionaries / linked blocks
+    void* (*dict_create)(void*, const uint8_t*, int);
+    void  (*dict_destroy)(void*, void*);
+    int (*compress_batch_dict)(void*, int, const void* const*, const int32_t*, void* const*, const int32_t*, int, void*, int32_t*);
+    int (*decompress_batch_dict)(void*, int, const void* const*, const int32_t*, void* const*, const int32_t*, void*, int32_t*);
+    int (*encode_records_ex)(void*, int, const void* const*, const int32_t*, int, int, int, int, void*, const void*, int, void* const*, int32_t*);
+    int (*decode_records_ex)(void*, int, const void* const*, const int32_t*, int, int, int, void*, void*, int*, void* const*, int32_t*, int32_t*);
 };
 std::unique_ptr<BlockEngine> NewVTableEngine(const EngineVTable& vt);
 
@@ -127,7 +144,9 @@ std::unique_ptr<Reader> NewReader(Source& rd, BlockEngine& eng, const Options& o
 
 // ---- raw block API (plz4_block.go:78-172)
 int   CompressBlockBound(int sz);
-Error CompressBlock(BlockEngine& eng, const uint8_t* src, size_t n, int level, std::vector<uint8_t>* dst, bool dstProvided);
-Error DecompressBlock(BlockEngine& eng, const uint8_t* src, size_t n, std::vector<uint8_t>* dst, bool dstProvided);
+Error CompressBlock(BlockEngine& eng, const uint8_t* src, size_t n, int level, std::vector<uint8_t>* dst, bool dstProvided,
+                    const std::vector<uint8_t>* dict = nullptr);                                   // WithBlockDictionary
+Error DecompressBlock(BlockEngine& eng, const uint8_t* src, size_t n, std::vector<uint8_t>* dst, bool dstProvided,
+                      const std::vector<uint8_t>* dict = nullptr);
 
 }  // namespace plz4h

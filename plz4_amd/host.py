@@ -37,12 +37,13 @@ class _Opts(C.Structure):
                 ("block_checksum", C.c_int32), ("block_linked", C.c_int32), ("content_checksum", C.c_int32),
                 ("skip_content_sz", C.c_int32), ("has_dict_id", C.c_int32), ("dict_id", C.c_uint32),
                 ("block_size_idx", C.c_int32), ("gpu_batch", C.c_int32), ("fail_after_writes", C.c_int32),
-                ("fail_read_at", C.c_int64), ("has_dictionary", C.c_int32)]
+                ("fail_read_at", C.c_int64), ("has_dictionary", C.c_int32), ("dictionary", C.c_void_p),
+                ("dictionary_len", C.c_int64)]
 
 
 def make_opts(parallel=1, pending_size=0, level=1, content_size=None, read_offset=0, block_checksum=False,
               block_linked=False, content_checksum=True, content_size_check=True, dictionary_id=None,
-              block_size=BlockIdx4MB, gpu_batch=0, fail_after_writes=-1, fail_read_at=-1, dictionary=False):
+              block_size=BlockIdx4MB, gpu_batch=0, fail_after_writes=-1, fail_read_at=-1, dictionary=None):
     """Defaults == parseOpts (plz4_opts.go:238-255).  Keyword names follow the With* options."""
     o = _Opts()
     o.nparallel, o.pending_sz, o.level = parallel, pending_size, level
@@ -52,7 +53,13 @@ def make_opts(parallel=1, pending_size=0, level=1, content_size=None, read_offse
     o.skip_content_sz = int(not content_size_check)
     o.has_dict_id, o.dict_id = int(dictionary_id is not None), int(dictionary_id or 0)
     o.block_size_idx, o.gpu_batch = block_size, gpu_batch
-    o.fail_after_writes, o.fail_read_at, o.has_dictionary = fail_after_writes, fail_read_at, int(dictionary)
+    o.fail_after_writes, o.fail_read_at = fail_after_writes, fail_read_at
+    o.has_dictionary = int(dictionary is not None)
+    if dictionary is not None:
+        d = np.frombuffer(bytes(dictionary), dtype=np.uint8).copy() if not isinstance(dictionary, np.ndarray) else np.ascontiguousarray(dictionary)
+        o._dict_keep = d                                     # keep the bytes alive as long as the options
+        o.dictionary = d.ctypes.data if d.size else None
+        o.dictionary_len = d.size
     return o
 
 
@@ -82,8 +89,8 @@ def lib():
     L.plz4h_reader_progress.restype = C.c_size_t; L.plz4h_reader_progress.argtypes = [vp, C.POINTER(vp)]
     L.plz4h_reader_close.argtypes = [vp]; L.plz4h_reader_free.argtypes = [vp]
     L.plz4h_compress_block_bound.argtypes = [C.c_int]
-    L.plz4h_compress_block.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, szp]
-    L.plz4h_decompress_block.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, szp]
+    L.plz4h_compress_block.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, szp, vp, C.c_int64]
+    L.plz4h_decompress_block.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, szp, vp, C.c_int64]
     L.plz4h_write_header.argtypes = [C.POINTER(_Opts), vp]
     L.plz4h_xxh32.restype = C.c_uint32; L.plz4h_xxh32.argtypes = [vp, C.c_size_t]
     L.plz4h_error_string.restype = C.c_char_p; L.plz4h_error_string.argtypes = [C.c_int]
@@ -201,21 +208,30 @@ def compress_block_bound(n: int) -> int:
     return int(lib().plz4h_compress_block_bound(n))
 
 
-def compress_block(engine: Engine, src, level=1, dst_cap=None):
-    """plz4.CompressBlock (plz4_block.go:96-119); dst_cap=None == no WithBlockDst."""
+def _dict_args(dictionary):
+    if dictionary is None:
+        return None, None, -1
+    d, dp = _buf(dictionary)
+    return d, dp, d.size
+
+
+def compress_block(engine: Engine, src, level=1, dst_cap=None, dictionary=None):
+    """plz4.CompressBlock (plz4_block.go:96-119); dst_cap=None == no WithBlockDst; dictionary == WithBlockDictionary."""
     a, p = _buf(src)
+    dk, dp, dl = _dict_args(dictionary)
     cap = compress_block_bound(a.size) if dst_cap is None else dst_cap
     out = np.empty(max(cap, 1), dtype=np.uint8); n = C.c_size_t(0)
-    e = Err(lib().plz4h_compress_block(engine.h, p, a.size, level, out.ctypes.data, cap, int(dst_cap is not None), C.byref(n)))
+    e = Err(lib().plz4h_compress_block(engine.h, p, a.size, level, out.ctypes.data, cap, int(dst_cap is not None), C.byref(n), dp, dl))
     return (out[:n.value].tobytes() if not e else None), e
 
 
-def decompress_block(engine: Engine, src, dst_cap=None, max_out=1 << 27):
+def decompress_block(engine: Engine, src, dst_cap=None, max_out=1 << 27, dictionary=None):
     """plz4.DecompressBlock (plz4_block.go:125-172); dst_cap=None == no WithBlockDst (4x, doubling, 3 tries)."""
     a, p = _buf(src)
+    dk, dp, dl = _dict_args(dictionary)
     cap = max_out if dst_cap is None else dst_cap
     out = np.empty(max(cap, 1), dtype=np.uint8); n = C.c_size_t(0)
-    e = Err(lib().plz4h_decompress_block(engine.h, p, a.size, out.ctypes.data, cap, int(dst_cap is not None), C.byref(n)))
+    e = Err(lib().plz4h_decompress_block(engine.h, p, a.size, out.ctypes.data, cap, int(dst_cap is not None), C.byref(n), dp, dl))
     return (out[:n.value].tobytes() if not e else None), e
 
 

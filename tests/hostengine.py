@@ -13,7 +13,7 @@ SO = os.path.join(ROOT, "tests", "hostlib", "_build", "liboracle_engine.so")
 
 
 class _VT(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("f", C.c_void_p * 4)]
+    _fields_ = [("user", C.c_void_p), ("f", C.c_void_p * 10)]
 
 
 _keep = []

@@ -8,7 +8,8 @@ from test_host_layer import (  # noqa: F401
     test_uncompressable_blocks_are_stored, test_empty_input_sync_vs_async, test_flush_makes_short_blocks,
     test_progress_and_read_offset, test_writer_sink_failures, test_short_read, test_content_crc,
     test_block_crc_and_size_overflow, test_concatenated_and_skippable_frames, test_read_small_chunks_matches_write_to,
-    test_corrupt_block_payload_is_lz4_corrupted, test_block_api, test_unsupported_modes_fail_loudly)
+    test_corrupt_block_payload_is_lz4_corrupted, test_block_api, test_unsupported_modes_fail_loudly,
+    test_writer_dict_and_linked_roundtrip, test_dictionary_makes_small_payloads_smaller)
 
 pytestmark = pytest.mark.gpu
 

@@ -174,10 +174,60 @@ def test_write_after_close(eng):
 
 
 def test_unsupported_modes_fail_loudly(eng):
-    for kw in (dict(level=9), dict(block_linked=True), dict(dictionary=True)):
+    """HC levels are not built yet: the writer reports ErrUnsupported, it never falls back to other bytes."""
+    for kw in (dict(level=9), dict(level=12, block_linked=True)):
         w = host.Writer(eng, parallel=1, **kw)
         w.write(b"some payload that needs compressing")
         assert int(w.close()) == host.ErrUnsupported
+
+
+# ------------------------------------------------------------------------------------------------ config 5 (wr_test.go: dict, linked, linked_with_dict)
+DICT = synth.text(70000, seed=321).tobytes()
+
+
+@pytest.mark.parametrize("case", ["dict", "linked", "linked_with_dict"])
+@pytest.mark.parametrize("bs", [host.BlockIdx64KB, host.BlockIdx256KB])
+def test_writer_dict_and_linked_roundtrip(eng, case, bs):
+    kw = dict(block_size=bs, block_checksum=True)
+    if "dict" in case:
+        kw["dictionary"] = DICT
+    if "linked" in case:
+        kw["block_linked"] = True
+    payload = (DICT[5000:45000] + synth.make("M", 900000, 64 << 10, seed=8).tobytes())
+    frames = []
+    for par, batch in ((1, 0), (4, 2), (0, 3)):              # different batch splits must not change a byte
+        w = host.Writer(eng, parallel=par, gpu_batch=batch, **kw)
+        for o in range(0, len(payload), 100000):
+            assert w.write(payload[o:o + 100000])[1] == 0
+        assert not w.close()
+        frames.append(w.output())
+    assert frames[0] == frames[1] == frames[2]
+    flg = frames[0][4]
+    assert bool(flg & 0x20) == ("linked" not in case)
+    rkw = {"dictionary": DICT} if "dict" in case else {}
+    for batch in (0, 1, 3):
+        n, out, err = host.Reader(eng, frames[0], gpu_batch=batch, **rkw).write_to()
+        assert not err and out == payload
+    if "dict" in case:                                       # the dictionary is really used: decoding without it fails or differs
+        n, out, err = host.Reader(eng, frames[0]).write_to()
+        assert err or out != payload
+    if "linked" in case:
+        n, out, err = host.Reader(eng, frames[0], read_offset=7 + 4, **rkw).write_to()
+        assert int(err) in (host.ErrReadOffsetLinked, host.ErrReadOffset)
+
+
+def test_dictionary_makes_small_payloads_smaller(eng):
+    """README.md:29 use case: many small payloads sharing a dictionary."""
+    msg = DICT[10000:10400]                                   # inside the last 64 KiB, the part liblz4 keeps
+    plain, e1 = host.compress_block(eng, msg)
+    withd, e2 = host.compress_block(eng, msg, dictionary=DICT)
+    assert not e1 and not e2 and len(withd) < len(plain) // 3
+    back, e = host.decompress_block(eng, withd, dictionary=DICT)
+    assert not e and back == msg
+    back, e = host.decompress_block(eng, withd, dst_cap=len(msg), dictionary=DICT)
+    assert not e and back == msg
+    bad, e = host.decompress_block(eng, withd, dst_cap=len(msg))
+    assert e or bad != msg
 
 
 # ------------------------------------------------------------------------------------------------ reader (rd_test.go)
