@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("PLZ4_BENCH_BLOCKS", "6144")),
                     help="4 MiB blocks per GPU per step")
     ap.add_argument("--kind", default="T")
+    ap.add_argument("--pipe", type=int, default=int(os.environ.get("PLZ4_BENCH_PIPE", "1")),
+                    help="parts per step; decode of part p overlaps encode of part p+1 on a second stream (1 = serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -158,15 +160,29 @@ def main():
         d_src[lo:lo + n] = rep[:n]
     del rep
     stride = eng.stage_stride(BSZ)
-    d_stage = torch.empty(B * stride, dtype=torch.uint8, device=dev)
-    d_len = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
-    d_body = torch.empty(B * (BSZ + 8), dtype=torch.uint8, device=dev)
     d_out = torch.empty(S, dtype=torch.uint8, device=dev)
-    d_res = torch.zeros(B, dtype=torch.int32, device=dev)
-    d_st = torch.zeros(B, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-    log("rank %d: %d blocks (%.1f GiB) ready in %.1fs" % (rank, B, S / 2**30, time.time() - t0))
+    # The batch is processed as `pipe` consecutive parts (like a writer emitting batch after batch): part p+1 is encoded
+    # while part p is decoded on a second HIP stream -- the decoder needs no LDS and fills issue slots the LDS-bound
+    # encoder leaves idle.  Every part has its own staging / sizes / offsets / body.
+    NP = max(1, min(args.pipe, B))
+    bounds = [(B * i) // NP for i in range(NP + 1)]
+    parts = []
+    for i in range(NP):
+        b0, b1 = bounds[i], bounds[i + 1]; nb = b1 - b0
+        parts.append({
+            "b0": b0, "nb": nb, "bytes": nb * BSZ,
+            "src": d_src[b0 * BSZ:b1 * BSZ], "out": d_out[b0 * BSZ:b1 * BSZ],
+            "stage": torch.empty(nb * stride, dtype=torch.uint8, device=dev),
+            "len": torch.zeros(nb, dtype=torch.int32, device=dev),
+            "off": torch.zeros(nb + 1, dtype=torch.int64, device=dev),
+            "body": torch.empty(nb * (BSZ + 8), dtype=torch.uint8, device=dev),
+            "res": torch.zeros(nb, dtype=torch.int32, device=dev),
+            "st": torch.zeros(nb, dtype=torch.int32, device=dev),
+        })
+    s_enc = torch.cuda.current_stream()
+    s_dec = torch.cuda.Stream(device=dev) if NP > 1 else s_enc
+    stream = s_enc.cuda_stream
+    log("rank %d: %d blocks (%.1f GiB) in %d part(s) ready in %.1fs" % (rank, B, S / 2**30, NP, time.time() - t0))
 
     gather = {}
 
@@ -175,36 +191,47 @@ def main():
                                 dst.data_ptr(), dst.numel(), stream)
         gather.setdefault("live", []).append((src_off, lens, dst_off))      # keep operands alive until the step ends
 
-    def frame_gather():
+    def frame_gather(pt):
         """N > 1: rank 0 owns the io.Writer.  All-gather the record sizes (tiny), send every body to rank 0 over xGMI
         (RCCL send/recv), interleave there: global block g = j*N + r is record j of rank r (plz4_amd/shard.py)."""
         from plz4_amd import shard
-        gather["live"] = []
-        total_local = int(d_off[-1].item())
-        shard.gather_frame_body(d_body[:max(total_local, 1)], d_len, rank, world, scatter, gather, BSZ + 8)
+        total_local = int(pt["off"][-1].item())
+        shard.gather_frame_body(pt["body"][:max(total_local, 1)], pt["len"], rank, world, scatter, gather, BSZ + 8)
 
     def step(ev=None):
-        if ev: ev[0].record()
-        eng.dev_encode_records(d_src.data_ptr(), S, BSZ, True, d_stage.data_ptr(), d_len.data_ptr(), stream)
-        if ev: ev[1].record()
-        eng.dev_compact_records(d_stage.data_ptr(), stride, d_len.data_ptr(), B, d_off.data_ptr(), d_body.data_ptr(),
-                                d_body.numel(), stream)
-        if ev: ev[2].record()
-        if world > 1:
-            frame_gather()
-        if ev: ev[3].record()
-        eng.dev_decode_records(d_body.data_ptr(), d_off.data_ptr(), B, BSZ, True, d_out.data_ptr(), BSZ, BSZ,
-                               d_res.data_ptr(), d_st.data_ptr(), stream)
-        if ev: ev[4].record()
+        """ev: per part [enc0, enc1, cmp1, gat1, dec0, dec1] events."""
+        gather["live"] = []
+        for i, pt in enumerate(parts):
+            e = ev[i] if ev else None
+            if e: e[0].record(s_enc)
+            eng.dev_encode_records(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["stage"].data_ptr(), pt["len"].data_ptr(), s_enc.cuda_stream)
+            if e: e[1].record(s_enc)
+            eng.dev_compact_records(pt["stage"].data_ptr(), stride, pt["len"].data_ptr(), pt["nb"], pt["off"].data_ptr(),
+                                    pt["body"].data_ptr(), pt["body"].numel(), s_enc.cuda_stream)
+            if e: e[2].record(s_enc)
+            if world > 1:
+                frame_gather(pt)
+            ready = torch.cuda.Event(enable_timing=False) if e is None else e[3]
+            ready.record(s_enc)
+            if s_dec is not s_enc:
+                s_dec.wait_event(ready)
+            if e: e[4].record(s_dec)
+            eng.dev_decode_records(pt["body"].data_ptr(), pt["off"].data_ptr(), pt["nb"], BSZ, True, pt["out"].data_ptr(), BSZ, BSZ,
+                                   pt["res"].data_ptr(), pt["st"].data_ptr(), s_dec.cuda_stream)
+            if e: e[5].record(s_dec)
+        if s_dec is not s_enc:
+            done = torch.cuda.Event(); done.record(s_dec); s_enc.wait_event(done)
 
     # ---- correctness gate before any timing: round trip bit-exact, every block status OK, records == oracle
     d_out.zero_()
+    torch.cuda.synchronize()
     step()
     torch.cuda.synchronize()
-    assert int(d_st.abs().sum().item()) == 0, "decode status != OK"
-    assert int(d_res.to(torch.int64).sum().item()) == S, "decoded size mismatch"
+    assert sum(int(pt["st"].abs().sum().item()) for pt in parts) == 0, "decode status != OK"
+    assert sum(int(pt["res"].to(torch.int64).sum().item()) for pt in parts) == S, "decoded size mismatch"
     assert torch.equal(d_out, d_src), "round trip mismatch"
-    C_bytes = int(d_off[-1].item())
+    C_bytes = sum(int(pt["off"][-1].item()) for pt in parts)
+    d_off, d_body = parts[0]["off"], parts[0]["body"]
     if rank == 0:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orclib
@@ -221,7 +248,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    evs = [[[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in parts] for _ in range(args.steps)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -231,7 +258,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    seg = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(4)] for e in evs])     # ms: enc, compact, gather, dec
+    # ms per step, summed over the parts: encode kernel, scan+compact, gather, decode kernel (decode overlaps the next encode)
+    seg = np.array([[sum(e[0].elapsed_time(e[1]) for e in st_), sum(e[1].elapsed_time(e[2]) for e in st_),
+                     sum(e[2].elapsed_time(e[3]) for e in st_), sum(e[4].elapsed_time(e[5]) for e in st_)] for st_ in evs])
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
@@ -255,7 +284,7 @@ def main():
                                    "(64 MiB PCG64/Zipf pool, rotated replicas), level 1, block checksum on, content "
                                    "checksum off; step = encode->frame body->decode, inputs resident in HBM"
                                    % (B, args.kind),
-                       "blocks_per_gpu": B, "block_bytes": BSZ, "stored_ratio": round(C_bytes / S, 4),
+                       "blocks_per_gpu": B, "block_bytes": BSZ, "pipeline_parts": NP, "stored_ratio": round(C_bytes / S, 4),
                        "sharding": "block i -> rank i mod N" if world > 1 else "single GPU"},
             "enc_MiBps_per_gpu": round(mib / (enc_ms * 1e-3), 1),
             "dec_MiBps_per_gpu": round(mib / (dec_ms * 1e-3), 1),
