@@ -183,7 +183,7 @@ class Engine:
         return out
 
     # ---- B. frame records over host buffers
-    def encode_records(self, srcs, bsz: int, block_checksum: bool, level: int = 1):
+    def encode_records(self, srcs, bsz: int, block_checksum: bool, level: int = 1):  # level 1 or 10..12
         n = len(srcs)
         lens = _i32([s.size for s in srcs])
         recs = [np.empty(bsz + 8, dtype=np.uint8) for _ in range(n)]

@@ -208,7 +208,8 @@ class WriterImpl : public Writer {
     }
     Error supported() const
     {
-        if (o.Level != 1) return E(ErrUnsupported);          // HC levels: next round
+        const bool opt = o.Level >= 10 && o.Level <= 12;     // lz4opt levels are built; 2..9 are not
+        if (o.Level != 1 && !(opt && !exMode())) return E(ErrUnsupported);
         return Error();
     }
     // blk.CompressToBlk x n on the engine, then in-order emission (async/writer.go:284-381 writeLoop)

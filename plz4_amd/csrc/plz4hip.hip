@@ -17,6 +17,7 @@
 __device__ unsigned long long plz4_stats[24];
 #endif
 #include "lz4_device.inl"
+#include "lz4hc_device.inl"
 
 namespace {
 
@@ -38,6 +39,9 @@ struct CodecArgs {
     int             linked;                         // encode: block i>0 is primed with the tail of block i-1
     const uint8_t*  prevTail;   int prevTailLen;    // linked: window of block 0 (-1: block 0 starts a frame)
     uint8_t*        window;     int* windowLen;     // linked decode: the 64 KiB sliding dictionary (2 x 64 KiB ping-pong), in/out
+    // HC levels 10..12
+    int             level;
+    uint8_t*        hcWork;                         // gridDim.x x kHcWorkBytes
 };
 
 __device__ __forceinline__ int next_block(uint32_t* q)
@@ -222,6 +226,45 @@ __global__ __launch_bounds__(64) void k_decode_raw_dict(CodecArgs a)
     }
 }
 
+// HC optimal parser, levels 10..12 (config 4): LZ4_compress_HC per block; mode 0 = raw LZ4 block, 1 = frame record.
+__device__ __forceinline__ HcWork hc_work_of(const CodecArgs& a)
+{
+    uint8_t* ws = a.hcWork + (size_t)blockIdx.x * kHcWorkBytes;
+    HcWork w; w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + kHcHashEntries * 4);
+    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2);
+    return w;
+}
+__global__ __launch_bounds__(64) void k_encode_raw_hc(CodecArgs a)
+{
+    const HcWork w = hc_work_of(a);
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
+        const int r = hc_compress_opt(a.src + (int64_t)i * a.srcStride, block_len(a, i), a.dst + (int64_t)i * a.dstStride, cap, a.level, w);
+        if ((threadIdx.x & 63u) == 0) a.result[i] = r;
+    }
+}
+__global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
+{
+    const HcWork w = hc_work_of(a);
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int      n   = block_len(a, i);
+        const uint8_t* s   = a.src + (int64_t)i * a.srcStride;
+        uint8_t*       rec = a.dst + (int64_t)i * a.dstStride;
+        int      c    = hc_compress_opt(s, n, rec + 4, a.bsz, a.level, w);   // capacity == bsz (blk.go:73); indie.go:80-88
+        uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
+        WAVE_FENCE();
+        if (c == 0) { wave_copy(rec + 4, s, n); c = n; word = 0x80000000u | ((uint32_t)n & 0x7FFFFFFFu); }
+        int len = c + 4;
+        if (a.blockChecksum) {
+            WAVE_FENCE();
+            const uint32_t x = wave_xxh32(rec + 4, c);
+            if ((threadIdx.x & 63u) == 0) st32u(rec + 4 + c, x);
+            len += 4;
+        }
+        if ((threadIdx.x & 63u) == 0) { st32u(rec, word); a.result[i] = len; }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_decode_raw(CodecArgs a)
 {
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
@@ -330,6 +373,7 @@ struct plz4hip_ctx {
     // host-API staging (grown on demand)
     uint8_t*     h_pin = nullptr;  size_t h_cap = 0;
     uint8_t*     d_buf = nullptr;  size_t d_cap = 0;
+    uint8_t*     d_hc = nullptr;   int hcWaves = 0;     // HC workspace, one slot per resident HC wave (allocated on first use)
 };
 
 // == clz4.DictCtx (clz4.go:96-120): a private device copy of the last 64 KiB of the dictionary + the LZ4_loadDictSlow table.
@@ -400,6 +444,17 @@ int ensure_staging(plz4hip_ctx* c, size_t hostBytes, size_t devBytes)
 
 int grid_for(int nBlocks, int resident) { return nBlocks < resident ? nBlocks : resident; }
 
+bool is_hc_level(int level) { return level >= 10 && level <= 12; }      // lz4opt rows of the level table (lz4hc.c:92-106)
+
+int ensure_hc(plz4hip_ctx* c)
+{
+    if (c->d_hc) return PLZ4HIP_OK;
+    const int waves = c->cus * 8;
+    if (hipMalloc((void**)&c->d_hc, (size_t)waves * kHcWorkBytes) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "HC workspace");
+    c->hcWaves = waves;
+    return PLZ4HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -468,6 +523,7 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     if (c->d_queues) hipFree(c->d_queues);
     if (c->h_pin) hipHostFree(c->h_pin);
     if (c->d_buf) hipFree(c->d_buf);
+    if (c->d_hc) hipFree(c->d_hc);
     delete c;
 }
 
@@ -517,7 +573,7 @@ int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes
                                int blockChecksum, void* stage, int32_t* recLen, void* stream)
 {
     if (!c || srcBytes < 0 || bsz <= 0 || !stage || !recLen) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_encode_records: bad argument");
-    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    if (level != 1 && !is_hc_level(level)) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1 and 10..12 are built");
     const int64_t nb64 = (srcBytes + bsz - 1) / bsz;
     if (nb64 > 0x7FFFFFFF) return fail(c, PLZ4HIP_E_ARG, "too many blocks");
     const int nBlocks = (int)nb64;
@@ -530,7 +586,13 @@ int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes
     a.src = (const uint8_t*)src; a.srcStride = bsz; a.srcBytes = srcBytes; a.bsz = bsz;
     a.dst = (uint8_t*)stage; a.dstStride = plz4hip_dev_stage_stride(bsz);
     a.result = recLen; a.queue = q; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
-    hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
+    if (is_hc_level(level)) {
+        if (int rc = ensure_hc(c)) return rc;
+        a.level = level; a.hcWork = c->d_hc;
+        hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nBlocks, c->hcWaves)), dim3(64), 0, s, a);
+    } else {
+        hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
+    }
     HIPCHK(c, hipGetLastError());
     return PLZ4HIP_OK;
 }
@@ -613,6 +675,7 @@ struct DictJob {                       // optional dictionary / linked parameter
     const void* prevTail = nullptr; int prevTailLen = -1;
     uint8_t* window = nullptr; int* windowLen = nullptr;      // host buffers (64 KiB) for the linked decode chain
     bool  any = false;
+    int   level = 1;
 };
 
 static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3 dec rec,4 xxh*/, int nBlocks,
@@ -650,7 +713,9 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     a.result = (int32_t*)(c->d_buf + st.offRes); a.status = (int32_t*)(c->d_buf + st.offSt);
     a.queue = q; a.nBlocks = nBlocks; a.bsz = bsz; a.blockChecksum = blockChecksum; a.dstCapAll = bsz + 8;
     const bool dictMode = dj && dj->any;
+    const bool hcMode = dj && is_hc_level(dj->level);
     a.dictLen = -1; a.prevTailLen = -1;
+    if (hcMode) { if (int rc = ensure_hc(c)) return rc; a.level = dj->level; a.hcWork = c->d_hc; }
     if (dictMode) {
         if (dj->dict) { a.dict = dj->dict->d_bytes; a.dictLen = dj->dict->len; a.dictTable = dj->dict->d_table; }
         a.linked = dj->linked;
@@ -668,12 +733,14 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         }
     }
     switch (mode) {
-    case 0: if (dictMode) hipLaunchKernelGGL(k_encode_raw_dict, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
+    case 0: if (hcMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nBlocks, c->hcWaves)), dim3(64), 0, s, a);
+            else if (dictMode) hipLaunchKernelGGL(k_encode_raw_dict, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
             else hipLaunchKernelGGL(k_encode_raw, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
     case 1: if (dictMode) hipLaunchKernelGGL(k_decode_raw_dict, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
             else hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a); break;
     case 2: a.dstCap = nullptr;
-            if (dictMode) hipLaunchKernelGGL(k_encode_rec_dict, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
+            if (hcMode) hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nBlocks, c->hcWaves)), dim3(64), 0, s, a);
+            else if (dictMode) hipLaunchKernelGGL(k_encode_rec_dict, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
             else hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
     case 3: a.dstCap = nullptr;
             if (dictMode && dj->linked) hipLaunchKernelGGL(k_decode_rec_linked, dim3(1), dim3(64), 0, s, a);
@@ -709,7 +776,8 @@ int plz4hip_compress_batch(plz4hip_ctx* c, int nBlocks, const void* const* src, 
                            void* const* dst, const int32_t* dstCap, int level, int32_t* result)
 {
     if (!c || nBlocks < 0 || (nBlocks && (!src || !srcLen || !dst || !dstCap || !result))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_compress_batch: bad argument");
-    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    if (is_hc_level(level)) { DictJob j; j.level = level; return host_codec(c, 0, nBlocks, src, srcLen, dst, dstCap, 0, 0, result, nullptr, &j); }
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1 and 10..12 are built");
     return host_codec(c, 0, nBlocks, src, srcLen, dst, dstCap, 0, 0, result, nullptr);
 }
 
@@ -730,8 +798,9 @@ int plz4hip_encode_records(plz4hip_ctx* c, int nBlocks, const void* const* src, 
                            int bsz, int level, int blockChecksum, void* const* rec, int32_t* recLen)
 {
     if (!c || nBlocks < 0 || bsz <= 0 || (nBlocks && (!src || !srcLen || !rec || !recLen))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_encode_records: bad argument");
-    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
     for (int i = 0; i < nBlocks; ++i) if (srcLen[i] > bsz) return fail(c, PLZ4HIP_E_ARG, "source block larger than block size");
+    if (is_hc_level(level)) { DictJob j; j.level = level; return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr, &j); }
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1 and 10..12 are built");
     return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr);
 }
 

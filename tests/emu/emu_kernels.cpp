@@ -3,6 +3,7 @@
 // Test infrastructure only: built into tests/emu/_build/, never loaded by plz4_amd, not a CPU fallback.
 #define PLZ4_EMU 1
 #include "../../plz4_amd/csrc/lz4_device.inl"
+#include "../../plz4_amd/csrc/lz4hc_device.inl"
 #include <stdlib.h>
 
 int plz4_emu_descending = 0;
@@ -23,6 +24,16 @@ int emu_decode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
 }
 
 uint32_t emu_xxh32(const uint8_t* p, int n) { return plz4::wave_xxh32(p, n); }
+
+int emu_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level)
+{
+    static thread_local uint8_t* ws = nullptr;
+    if (!ws) ws = (uint8_t*)malloc(plz4::kHcWorkBytes);
+    plz4::HcWork w;
+    w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + plz4::kHcHashEntries * 4);
+    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2);
+    return plz4::hc_compress_opt(src, n, dst, cap, level, w);
+}
 
 int emu_encode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, const uint8_t* dict, int dictSize, int mode,
                           const uint32_t* dictTable)

@@ -12,7 +12,7 @@ from orclib import ROOT, _ptr, u8p
 
 EMU_SRC = os.path.join(ROOT, "tests", "emu", "emu_kernels.cpp")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "_build", "libemu.so")
-DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "wave.h")]
+DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "lz4hc_device.inl", "wave.h")]
 
 
 def build_emu():
@@ -50,6 +50,13 @@ class Emu:
     def decompress_dict(self, src, cap, dct):
         dst = np.zeros(max(cap, 1) + 32, dtype=np.uint8)
         r = int(self.L.emu_decode_block_dict(_ptr(src), src.size, _ptr(dst), cap, _ptr(dct), dct.size))
+        return r, dst[:max(r, 0)]
+
+    def compress_hc(self, src, cap, level):
+        self.L.emu_compress_hc.restype = C.c_int
+        self.L.emu_compress_hc.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int]
+        dst = np.empty(max(cap, 1) + 32, dtype=np.uint8)
+        r = int(self.L.emu_compress_hc(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, level))
         return r, dst[:max(r, 0)]
 
     def set_descending(self, d: bool):

@@ -70,6 +70,17 @@ def main():
             blocks.append({"kind": kind, "bsz": bsz, "index": i, "src_sha": sha(blk), "ret": r, "comp_sha": sha(c) if r else None})
     json.dump({"reference": "liblz4 1.10.0", "blocks": blocks}, open(os.path.join(HERE, "block_digests.json"), "w"), indent=0)
 
+    # ---- HC optimal-parser levels (config 4 = level 12): LZ4_compress_HC of the real reference
+    hc = []
+    for kind, bsz, nblk, levels in (("T", 64 << 10, 4, (10, 11, 12)), ("M", 256 << 10, 3, (10, 11, 12)), ("T", 4 << 20, 1, (12,))):
+        data = synth.make(kind, nblk * bsz, bsz)
+        for i in range(nblk):
+            blk = data[i * bsz:(i + 1) * bsz]
+            for lvl in levels:
+                r, c = ref.compress_hc(blk, bsz, lvl)
+                hc.append({"kind": kind, "bsz": bsz, "index": i, "level": lvl, "src_sha": sha(blk), "ret": r, "comp_sha": sha(c) if r else None})
+    json.dump({"reference": "liblz4 1.10.0 LZ4_compress_HC", "blocks": hc}, open(os.path.join(HERE, "hc_digests.json"), "w"), indent=0)
+
     # ---- config 1 frame (sync writer semantics; per-block arithmetic checked against the reference here)
     data = synth.text(16 << 20)
     bsz = 64 << 10
