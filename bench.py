@@ -51,7 +51,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(pool: np.ndarray, seconds: float = 12.0):
+def cpu_baseline(pool: np.ndarray, seconds: float = 12.0, level: int = 1):
     """plz4's CPU path for the same per-block work (LZ4_compress_fast cap=bsz -> stored fallback -> xxh32, then
     verify xxh32 + LZ4_decompress_safe into bsz+8), one block per task on all host cores.  Uses the compiled
     reference liblz4 (oracle/_ref) when present, else the oracle restatement."""
@@ -66,11 +66,12 @@ def cpu_baseline(pool: np.ndarray, seconds: float = 12.0):
     if os.path.exists(orclib.REF_SO):
         ref = orclib.Ref()
         kind = "reference"
-        enc = lambda s, d: ref.L.LZ4_compress_fast(s, d, BSZ, BSZ, 1)
+        enc = (lambda s, d: ref.L.LZ4_compress_fast(s, d, BSZ, BSZ, 1)) if level == 1 else \
+              (lambda s, d: ref.L.LZ4_compress_HC(s, d, BSZ, BSZ, level))
         dec = lambda s, n, d: ref.L.LZ4_decompress_safe(s, d, n, BSZ + 8)
     cores = os.cpu_count() or 1
     npool = pool.size // BSZ
-    nblk = max(npool, 2 * cores)                                             # at least two tasks per hardware thread
+    nblk = max(npool, 2 * cores) if level == 1 else max(npool, cores)        # at least one (HC) / two tasks per hardware thread
     srcs = [np.ascontiguousarray(pool[(i % npool) * BSZ:(i % npool + 1) * BSZ]) for i in range(npool)]
     comp = [np.empty(BSZ + 8, dtype=np.uint8) for _ in range(nblk)]
     outs = [np.empty(BSZ + 8, dtype=np.uint8) for _ in range(nblk)]
@@ -121,6 +122,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("PLZ4_BENCH_BLOCKS", "6144")),
                     help="4 MiB blocks per GPU per step")
     ap.add_argument("--kind", default="T")
+    ap.add_argument("--level", type=int, default=1, help="1 (configs[1]/[2], the headline) or 10..12 (configs[3]: HC optimal parser)")
     ap.add_argument("--pipe", type=int, default=int(os.environ.get("PLZ4_BENCH_PIPE", "1")),
                     help="parts per step; decode of part p overlaps encode of part p+1 on a second stream (1 = serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -204,7 +206,8 @@ def main():
         for i, pt in enumerate(parts):
             e = ev[i] if ev else None
             if e: e[0].record(s_enc)
-            eng.dev_encode_records(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["stage"].data_ptr(), pt["len"].data_ptr(), s_enc.cuda_stream)
+            eng.dev_encode_records(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["stage"].data_ptr(), pt["len"].data_ptr(), s_enc.cuda_stream,
+                                   level=args.level)
             if e: e[1].record(s_enc)
             eng.dev_compact_records(pt["stage"].data_ptr(), stride, pt["len"].data_ptr(), pt["nb"], pt["off"].data_ptr(),
                                     pt["body"].data_ptr(), pt["body"].numel(), s_enc.cuda_stream)
@@ -238,8 +241,14 @@ def main():
         orc = orclib.Oracle()
         offs = d_off[:3].cpu().tolist()
         for i in range(2):
-            want = orc.block_record(d_src[i * BSZ:(i + 1) * BSZ].cpu().numpy(), BSZ, True)
+            blk = d_src[i * BSZ:(i + 1) * BSZ].cpu().numpy()
             got = d_body[offs[i]:offs[i + 1]].cpu().numpy()
+            if args.level == 1:
+                want = orc.block_record(blk, BSZ, True)
+            else:                                                            # HC: the compiled reference is the checker
+                r_, c_ = orclib.Ref().compress_hc(blk, BSZ, args.level)
+                want = np.concatenate([np.frombuffer(np.uint32(r_).tobytes(), dtype=np.uint8), c_,
+                                       np.frombuffer(np.uint32(orc.xxh32(c_)).tobytes(), dtype=np.uint8)])
             assert np.array_equal(want, got), "record %d differs from the oracle" % i
         log("parity gate ok: round trip exact, 2 records == oracle, stored/plain ratio %.4f" % (C_bytes / S))
 
@@ -273,24 +282,24 @@ def main():
         ach_enc = (S + C_bytes) / (enc_ms * 1e-3) / 1e9
         ach_dec = (S + C_bytes) / (dec_ms * 1e-3) / 1e9
         out = {
-            "metric": "MiB/s enc+dec, 4MiB independent blocks, level 1, block-checksum on",
+            "metric": "MiB/s enc+dec, 4MiB independent blocks, level %d, block-checksum on" % args.level,
             "value": round(world * mib / (ms_step * 1e-3), 1),
             "unit": "MiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "configs[1]+[2]: %d x 4MiB independent blocks per GPU of synthetic %s text "
-                                   "(64 MiB PCG64/Zipf pool, rotated replicas), level 1, block checksum on, content "
+            "config": {"workload": ("configs[1]+[2]" if args.level == 1 else "configs[3] (HC)") + ": %d x 4MiB independent blocks per GPU of synthetic %s text "
+                                   "(64 MiB PCG64/Zipf pool, rotated replicas), level %d, block checksum on, content "
                                    "checksum off; step = encode->frame body->decode, inputs resident in HBM"
-                                   % (B, args.kind),
+                                   % (B, args.kind, args.level),
                        "blocks_per_gpu": B, "block_bytes": BSZ, "pipeline_parts": NP, "stored_ratio": round(C_bytes / S, 4),
                        "sharding": "block i -> rank i mod N" if world > 1 else "single GPU"},
             "enc_MiBps_per_gpu": round(mib / (enc_ms * 1e-3), 1),
             "dec_MiBps_per_gpu": round(mib / (dec_ms * 1e-3), 1),
             "ms": {"encode_kernel": round(enc_ms, 3), "scan_compact": round(cmp_ms, 3),
                    "frame_gather": round(gat_ms, 3), "decode_kernel": round(dec_ms, 3)},
-            "roofline": {"bound": "hbm", "kernel": "k_encode_rec", "achieved": round(ach_enc, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_encode_rec" if args.level == 1 else "k_encode_rec_hc", "achieved": round(ach_enc, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(ach_enc / HBM_PEAK_GBS, 5), "traffic": None},
             "roofline_decode": {"bound": "hbm", "kernel": "k_decode_rec", "achieved": round(ach_dec, 2),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_dec / HBM_PEAK_GBS, 5),
@@ -301,7 +310,7 @@ def main():
             if t:
                 out[key]["traffic"] = t["bytes"]; out[key]["traffic_source"] = t["source"]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pool)
+            out["cpu_baseline"] = cpu_baseline(pool, level=args.level)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
