@@ -192,10 +192,11 @@ DEV int emit_len_ext(uint8_t* dst, int op, int rest)
 // x-1), seq = [x, x+8), f1 = [x+8, x+16), f2 = [x+16, x+20).
 struct Win24 { uint32_t back; uint64_t seq; uint64_t f1; uint32_t f2; };
 
+template <bool kMayBeLow>
 DEV Win24 load_win24(const uint8_t* src, int x)
 {
     Win24 w;
-    if (x >= 4) {
+    if (!kMayBeLow || x >= 4) {
         const v16u_t a = *(const v16u_t*)(src + x - 4);           // [x-4, x+12)
         const uint64_t b = ld64u(src + x + 12);                     // [x+12, x+20)
         w.back = a.w[0];
@@ -294,7 +295,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
         int  sBase   = 1;  int  sIter  = 0;        // search started at sBase; next un-probed probe number
         int  width   = 16;                         // generic batches: 16 lanes first, 64 when a search drags on
         LV(Win24, Pn); int prefBase = -1;          // next window's bytes, requested one batch ahead
-        LANES({ Pn[I_].back = 0; Pn[I_].seq = 0; Pn[I_].f1 = 0; Pn[I_].f2 = 0; })
+        LV(Win24, Pc);                             // this window's bytes (kept: a wrong twin is repaired from them)
+        LANES({ Pn[I_].back = 0; Pn[I_].seq = 0; Pn[I_].f1 = 0; Pn[I_].f2 = 0; Pc[I_] = Pn[I_]; })
 
         for (;;) {
             // ================================================================ GRID batch
@@ -314,7 +316,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         const int isIns = hasIns && q == insPos;
                         act[I_] = isIns || q >= probeStart;
                         hit[I_] = 0; fwd[I_] = 0; bck[I_] = 0; r[I_] = 0; h[I_] = 0; ent[I_] = 0; rent[I_] = 0;
-                        const Win24 P = (base == prefBase) ? Pn[I_] : load_win24(src, q);   // every lane: its byte may be a pending literal
+                        const Win24 P = (base == prefBase) ? Pn[I_] : load_win24<false>(src, q);   // every lane: its byte may be a pending literal
+                        Pc[I_] = P;
                         lit8[I_] = (uint32_t)(P.seq & 0xFF);
                         if (act[I_]) {
                             h[I_] = seq_hash<false>(P.seq);
@@ -323,7 +326,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             rent[I_] = lds_max_rtn(&T[h[I_]], ent[I_]);
                             r[I_]    = rent[I_] >> sh;
                             if (!isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q && (rent[I_] & tagMask) == tg) {
-                                const Win24 Cw = load_win24(src, (int)r[I_]);
+                                const Win24 Cw = load_win24<true>(src, (int)r[I_]);
                                 if ((uint32_t)Cw.seq == (uint32_t)P.seq) {
                                     hit[I_] = 1;
                                     fwd[I_] = win_fwd(P, Cw);
@@ -332,7 +335,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             }
                         }
                         eLane[I_] = LANE + kMinMatch + fwd[I_];     // lane index just past a match that starts here
-                        if (base + 160 <= n) Pn[I_] = load_win24(src, q + 64);   // request the next window now, use it next batch
+                        if (base + 160 <= n) Pn[I_] = load_win24<false>(src, q + 64);   // request the next window now, use it next batch
                     })
                     prefBase = (base + 160 <= n) ? base + 64 : -1;
                     LDS_FENCE();
@@ -346,9 +349,10 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         goto generic_batch;
                     }
                     {
-                        const uint64_t hits  = BALLOT(hit[I_]);
-                        const uint64_t twins = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);    // earlier twin inside this batch
-                        uint64_t specialLeft = BALLOT(hit[I_] && (fwd[I_] == 16 || (bck[I_] == 4 && r[I_] > 4)));
+                        uint64_t hits  = BALLOT(hit[I_]);
+                        uint64_t twins = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);          // earlier twin inside this batch
+                        const uint64_t anyTwins = twins;                                          // (bits of repaired lanes get cleared below)
+                        uint64_t specialLeft = BALLOT(hit[I_] && fwd[I_] == 16);           // longer than the speculative window: the hop needs its end
                         const int  cur0 = probeStart - base;                  // first probe lane (>= 64: none in this batch)
                         const bool re0  = hasRe;
                         const uint64_t insBit0 = hasIns ? (1ull << (insPos - base)) : 0;
@@ -381,11 +385,6 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                         const int p0 = base + w, c0 = (int)RL(r, w);
                                         int mc0 = (int)RL(fwd, w);
                                         if (mc0 == 16) { STAT(S_SAT, 1); mc0 += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); WL(fwd, w, mc0); }
-                                        const bool isRe = mm ? (w == eL) : (re0 && w == cur0);
-                                        if (!isRe && (int)RL(bck, w) == 4) {
-                                            const int maxBack = min_(p0 - aCur, c0);
-                                            if (maxBack > 4) { STAT(S_LONGBACK, 1); WL(bck, w, 4 + wave_common_back(src, p0 - 4, c0 - 4, maxBack - 4)); }
-                                        }
                                         specialLeft &= ~(1ull << w);
                                         eL = w + kMinMatch + mc0;
                                         WL(eLane, w, eL);
@@ -418,10 +417,39 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             const uint64_t probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
                             E = probes | insBit0 | BALLOT(hasPm[I_] && stA[I_] == LANE + 2);   // + the ip-2 inserts (lz4.c:1236-1242)
                             if (twins & probes) {
-                                // a probe whose candidate is an earlier lane of this batch is only right if that lane was executed
+                                // A probe whose candidate is an earlier lane of this batch is only right if that lane was executed.
+                                // Otherwise the sequential parser saw what that lane displaced (or what *it* displaced, ...):
+                                // repair the first such lane in place and redo the (cheap) hop.
                                 const uint64_t EL = E;
                                 const uint64_t bad = twins & probes & BALLOT(!((EL >> (((int)r[I_] - base) & 63)) & 1));
-                                if (bad) { STAT(S_TWINSTOP, 1); S = ctz64(bad); continue; }
+                                if (bad) {
+                                    STAT(S_TWINSTOP, 1);
+                                    const int b = ctz64(bad);
+                                    uint32_t ce = RL(rent, b);                          // entry lane b displaced
+                                    for (;;) {
+                                        const uint32_t cp = ce >> sh;
+                                        if (cp < (uint32_t)firstPos) break;             // a pre-batch entry
+                                        const int t = (int)cp - base;
+                                        if ((E >> t) & 1) break;                        // an executed lane of this batch
+                                        ce = RL(rent, t);                               // a skipped lane: what it displaced
+                                    }
+                                    const uint32_t cp = ce >> sh, qb = (uint32_t)(base + b);
+                                    int nhit = 0, nfwd = 0, nbck = 0;
+                                    if (cp + kMaxDist >= qb && (ce & tagMask) == (RL(ent, b) & tagMask)) {
+                                        Win24 Pb; Pb.back = RLF(Pc, back, b); Pb.seq = RLF(Pc, seq, b); Pb.f1 = RLF(Pc, f1, b); Pb.f2 = RLF(Pc, f2, b);
+                                        Win24 Cw;
+                                        if (cp >= (uint32_t)base) { const int t = (int)cp - base; Cw.back = RLF(Pc, back, t); Cw.seq = RLF(Pc, seq, t); Cw.f1 = RLF(Pc, f1, t); Cw.f2 = RLF(Pc, f2, t); }
+                                        else { Cw = load_win24<true>(src, (int)cp); Cw.back = UNI(Cw.back); Cw.seq = UNI(Cw.seq); Cw.f1 = UNI(Cw.f1); Cw.f2 = UNI(Cw.f2); }
+                                        if ((uint32_t)Cw.seq == (uint32_t)Pb.seq) { nhit = 1; nfwd = win_fwd(Pb, Cw); nbck = min_(win_bck(Pb, Cw), (int)cp); }
+                                    }
+                                    WL(rent, b, ce); WL(r, b, cp); WL(hit, b, nhit); WL(fwd, b, nfwd); WL(bck, b, nbck);
+                                    WL(eLane, b, b + kMinMatch + nfwd);
+                                    const uint64_t bit = 1ull << b;
+                                    hits = nhit ? (hits | bit) : (hits & ~bit);
+                                    specialLeft = (nhit && nfwd == 16) ? (specialLeft | bit) : (specialLeft & ~bit);
+                                    twins &= ~bit;
+                                    continue;
+                                }
                             }
                             break;
                         }
@@ -433,9 +461,20 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             LV(int, anc); LV(int, lit); LV(int, mcT); LV(int, extL); LV(int, extM); LV(int, size); LV(int, tok);
                             LV(int, pS); LV(int, litDst);
                             const int anchor0 = anchor;
+                            LANES({ anc[I_] = hasPm[I_] ? base + stA[I_] : anchor0; })
+                            {   // catch-up that may go past the 4 speculative bytes (rare): finish it now that the anchors are final
+                                const uint64_t mmB = mm;
+                                uint64_t deep = BALLOT(((mmB >> LANE) & 1) && bck[I_] == 4 && min_(base + LANE - anc[I_], (int)r[I_]) > 4);
+                                for (; deep; deep &= deep - 1) {
+                                    const int w = ctz64(deep);
+                                    const int p0 = base + w, c0 = (int)RL(r, w);
+                                    const int maxBack = min_(p0 - RL(anc, w), c0);
+                                    STAT(S_LONGBACK, 1);
+                                    WL(bck, w, 4 + wave_common_back(src, p0 - 4, c0 - 4, maxBack - 4));
+                                }
+                            }
                             LANES({
                                 const int q = base + LANE;
-                                anc[I_] = hasPm[I_] ? base + stA[I_] : anchor0;
                                 const int bk = min_(bck[I_], min_(q - anc[I_], (int)r[I_]));     // lz4.c:1105-1109 (0 for a re-test)
                                 pS[I_]   = q - bk;
                                 lit[I_]  = q - bk - anc[I_];
@@ -451,7 +490,9 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                 op += RL(size, w);
                             }
                             const uint64_t mmL = mm;
-                            if (limited) {                                     // lz4.c:1114-1117 and :1187-1210, per sequence
+                            // lz4.c:1114-1117 and :1187-1210, per sequence.  Every left-hand side is <= (end of this batch's output) + 7,
+                            // so the exact per-sequence test is only needed near the end of the capacity.
+                            if (limited && (int64_t)op + 8 > cap) {
                                 const uint64_t over = BALLOT(((mmL >> LANE) & 1) &&
                                     ((!(hasPm[I_] ? (LANE == stA[I_]) : (re0 && LANE == cur0)) &&
                                       (int64_t)tok[I_] + 1 + lit[I_] + (2 + 1 + kLastLiterals) + lit[I_] / 255 > cap) ||
@@ -504,7 +545,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         // ---- 6. patch the table to the sequential result
                         const uint64_t EL2 = E;
                         LANES({ if (act[I_] && !((EL2 >> LANE) & 1)) lds_min(&T[h[I_]], rent[I_]); })
-                        if (twins) { LDS_FENCE(); LANES({ if ((EL2 >> LANE) & 1) lds_max(&T[h[I_]], ent[I_]); }) }
+                        if (anyTwins) { LDS_FENCE(); LANES({ if ((EL2 >> LANE) & 1) lds_max(&T[h[I_]], ent[I_]); }) }
                         LDS_FENCE();
                         width = 64;
                         continue;

@@ -28,6 +28,7 @@
 #define LANES(...)     for (int lane_ = plz4_emu_first(); lane_ != plz4_emu_end(); lane_ += plz4_emu_step()) { __VA_ARGS__ }
 #define BALLOT(c)      ([&]() { uint64_t m_ = 0; for (int lane_ = 0; lane_ < 64; ++lane_) if (c) m_ |= 1ull << lane_; return m_; }())
 #define RL(x, w)       ((x)[(w)])
+#define RLF(x, f, w)   ((x)[(w)].f)                     /* read field f of lane w of a per-lane struct */
 #define WL(x, w, v)    do { const auto wl_v_ = (v); (x)[(w)] = wl_v_; } while (0)   /* write one lane (uniform lane index) */
 #define SHFL(x, l)     ((x)[(l) & 63])                  /* read another lane's value (per-lane lane index) */
 #define UNI(x)         (x)
@@ -49,6 +50,7 @@ static inline int plz4_emu_step()  { return plz4_emu_descending ? -1 : 1; }
 #define LANES(...)     { __VA_ARGS__ }
 #define BALLOT(c)      ((uint64_t)__ballot((c)))
 #define RL(x, w)       plz4_readlane((x)[0], (w))
+#define RLF(x, f, w)   plz4_readlane((x)[0].f, (w))
 /* v is evaluated by the whole wave BEFORE the select (it may contain ballots); then v_cmp + v_cndmask */
 #define WL(x, w, v)    do { const auto wl_v_ = (v); (x)[0] = (LANE == (w)) ? wl_v_ : (x)[0]; } while (0)
 #define SHFL(x, l)     plz4_bpermute((x)[0], (l))
