@@ -33,7 +33,8 @@ extern __device__ unsigned long long plz4_stats[24];
 #define STAT_FLUSH() do {} while (0)
 #endif
 enum { S_GRID = 0, S_GENERIC, S_MISORDER, S_SEQ_GRID, S_SEQ_GEN, S_TWINSTOP, S_SAT, S_LONGBACK, S_MEMLIT, S_WALKITER,
-       S_CYC_TOTAL, S_CYC_LOAD, S_CYC_WALK, S_CYC_FIX, S_CYC_GEN, S_CYC_SAT, S_CYC_MEMLIT, S_BLOCKS, S_LANES_EXEC };
+       S_CYC_TOTAL, S_CYC_LOAD, S_CYC_WALK, S_CYC_FIX, S_CYC_GEN, S_CYC_SAT, S_CYC_MEMLIT, S_BLOCKS, S_LANES_EXEC,
+       S_DBATCH, S_DMEMB, S_DSEQ, S_DSEQ_ML15, S_DSEQ_LL15 };
 
 namespace plz4 {
 
@@ -1041,13 +1042,17 @@ DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t*
     if (cap == 0) return (n == 1 && UNI(src[0]) == 0) ? 0 : -1;
     if (n == 0) return -1;
     bool fast = (oend - op) >= 64;
+    STAT_DECL;
 
     for (;;) {
         if (fast && ip + 160 <= iend && op + 1088 <= oend) {
             WAVE_FENCE();
-            if (wave_decode_plain_batch(src, dst, &ip, &op) > 0) { WAVE_FENCE(); continue; }
+            const int nm = wave_decode_plain_batch(src, dst, &ip, &op);
+            STAT(S_DBATCH, 1); STAT(S_DMEMB, nm);
+            if (nm > 0) { WAVE_FENCE(); continue; }
         }
         const uint32_t token = UNI(src[ip]); ip++;
+        STAT(S_DSEQ, 1); STAT(S_DSEQ_ML15, (token & 15) == 15); STAT(S_DSEQ_LL15, (token >> 4) == 15);
         int64_t ll = token >> 4, ml; int offset; int64_t mpos;
 
         if (fast) {
@@ -1156,6 +1161,7 @@ dict_copy:                                                                   // 
             WAVE_FENCE();
         }
     }
+    STAT_FLUSH();
     return (int)op;
 }
 

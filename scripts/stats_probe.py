@@ -17,7 +17,8 @@ _native.LIB_PATH = so
 eng = _native.Engine(0)
 L = eng.L
 names = ["grid", "generic", "misorder", "seq_grid", "seq_gen", "twinstop", "sat", "longback", "memlit", "walkiter",
-         "cyc_total", "cyc_load", "cyc_walk", "cyc_fix", "cyc_gen", "cyc_sat", "cyc_memlit", "blocks", "lanes_exec"]
+         "cyc_total", "cyc_load", "cyc_walk", "cyc_fix", "cyc_gen", "cyc_sat", "cyc_memlit", "blocks", "lanes_exec",
+         "dbatch", "dmemb", "dseq", "dseq_ml15", "dseq_ll15"]
 bsz = 4 << 20
 pool = synth.text(16 * bsz)
 dev = torch.device("cuda:0")
@@ -44,3 +45,18 @@ for chk in (True, False):
     print("   per generic batch: %.0f cyc;  sat: %.0f cyc each; memlit: %.0f cyc each; total cyc/block %.3e"
           % (v["cyc_gen"] / max(v["generic"], 1), v["cyc_sat"] / max(v["sat"], 1), v["cyc_memlit"] / max(v["memlit"], 1),
              v["cyc_total"] / nb))
+
+# decode stats
+d_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+d_body = torch.empty(B * (bsz + 8), dtype=torch.uint8, device=dev)
+d_out = torch.empty(B * bsz, dtype=torch.uint8, device=dev)
+d_res = torch.zeros(B, dtype=torch.int32, device=dev); d_st = torch.zeros(B, dtype=torch.int32, device=dev)
+eng.dev_compact_records(d_stage.data_ptr(), stride, d_len.data_ptr(), B, d_off.data_ptr(), d_body.data_ptr(), d_body.numel(), 0)
+L.plz4hip_debug_stats(out)
+torch.cuda.synchronize(); t0 = time.time()
+eng.dev_decode_records(d_body.data_ptr(), d_off.data_ptr(), B, bsz, False, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), 0)
+torch.cuda.synchronize(); dt = time.time() - t0
+L.plz4hip_debug_stats(out)
+v = dict(zip(names, list(out)))
+print("decode B=%d %.1f ms -> %.1f MiB/s; per block: batches %.0f, members %.0f, sequential steps %.0f (ml15 %.0f, ll15 %.0f)"
+      % (B, dt * 1e3, B * 4 / dt, v["dbatch"] / B, v["dmemb"] / B, v["dseq"] / B, v["dseq_ml15"] / B, v["dseq_ll15"] / B))
