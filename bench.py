@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=int(os.environ.get("PLZ4_BENCH_BLOCKS", "6144")),
                     help="4 MiB blocks per GPU per step")
     ap.add_argument("--kind", default="T")
-    ap.add_argument("--level", type=int, default=1, help="1 (configs[1]/[2], the headline) or 10..12 (configs[3]: HC optimal parser)")
+    ap.add_argument("--level", type=int, default=1, help="1 (configs[1]/[2], the headline) or 2..12 (LZ4_compress_HC; configs[3] is level 12)")
     ap.add_argument("--pipe", type=int, default=int(os.environ.get("PLZ4_BENCH_PIPE", "1")),
                     help="parts per step; decode of part p overlaps encode of part p+1 on a second stream (1 = serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -63,9 +63,10 @@ int plz4hip_compress_bound(int n);
 /* ---------------------------------------------------------------------------------------------------------
  * A. Batched Compressor / Decompressor over HOST buffers (what the cgo shim calls).
  *    Replaces clz4.CompressFast (clz4.go:31-45) / clz4.DecompressSafe (clz4.go:47-60) x nBlocks.
- *    level: 1 (== LZ4_compress_fast(accel 1), compress/indie.go:66-74) and 10..12 (== LZ4_compress_HC(level), the
- *           optimal parser, compress/indie.go:80-88 -> clz4.CompressHC clz4.go:80-94 -> lz4hc.c:1519); 2..9 are not built
- *           (PLZ4HIP_E_UNSUPPORTED).  encode_records / dev_encode_records take the same levels.
+ *    level: 1 (== LZ4_compress_fast(accel 1), compress/indie.go:66-74) and 2..12 (== LZ4_compress_HC(level),
+ *           compress/indie.go:80-88 -> clz4.CompressHC clz4.go:80-94 -> lz4hc.c:1519: lz4mid at 2, hash chain at 3..9,
+ *           optimal parser at 10..12); anything else is PLZ4HIP_E_UNSUPPORTED.  encode_records / dev_encode_records
+ *           take the same levels.
  *    result[i]: encode  > 0 bytes written into dst[i], 0 = liblz4 "does not fit dstCap[i]";
  *               decode >= 0 bytes written, < 0 liblz4 error code.
  * ------------------------------------------------------------------------------------------------------- */

@@ -208,8 +208,8 @@ class WriterImpl : public Writer {
     }
     Error supported() const
     {
-        const bool opt = o.Level >= 10 && o.Level <= 12;     // lz4opt levels are built; 2..9 are not
-        if (o.Level != 1 && !(opt && !exMode())) return E(ErrUnsupported);
+        const bool hc = o.Level >= 2 && o.Level <= 12;       // HC levels: independent blocks without a dictionary only, so far
+        if (o.Level != 1 && !(hc && !exMode())) return E(ErrUnsupported);
         return Error();
     }
     // blk.CompressToBlk x n on the engine, then in-order emission (async/writer.go:284-381 writeLoop)

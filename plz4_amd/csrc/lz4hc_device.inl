@@ -1,10 +1,14 @@
-// lz4hc_device.inl -- LZ4 HC "optimal parser" levels 10..12 (BASELINE config 4 = level 12) for one independent block.
+// lz4hc_device.inl -- LZ4 HC, every level plz4 routes to LZ4_compress_HC (2..12), for one independent block.
 //
-//   hc_compress_opt  ==  LZ4_compress_HC(src, dst, n, cap, level)  for level in {10, 11, 12}
+//   hc_compress      ==  LZ4_compress_HC(src, dst, n, cap, level)
 //      /root/reference/internal/pkg/clz4/lz4hc.c:1519-1535 -> :1500-1510 -> :242-259 (init, indices start at 64 KiB)
-//      -> :1373-1415 -> LZ4HC_compress_optimal :1823-2123 with the level table :92-106
-//      match finder  LZ4HC_FindLongerMatch :1802-1820 -> LZ4HC_InsertAndGetWiderMatch :884-1104 (patternAnalysis, chainSwap),
-//      LZ4HC_Insert :781-802, pattern helpers :811-868, price model :1778-1800, LZ4HC_encodeSequence :268-354.
+//      -> :1373-1415 with the level table :92-106:
+//        level 2       hc_compress_mid    LZ4MID_compress :521-775 (two direct-mapped tables, 4- and 7-byte hashes)
+//        levels 3..9   hc_compress_chain  LZ4HC_compress_hashChain :1121-1363 (lazy 3-match parser over the hash chain)
+//        levels 10..12 hc_compress_opt    LZ4HC_compress_optimal :1823-2123 (BASELINE config 4 = level 12)
+//      match finder  LZ4HC_InsertAndGetWiderMatch :884-1104 (patternAnalysis, chainSwap, look-back), LZ4HC_FindLongerMatch
+//      :1802-1820, LZ4HC_Insert :781-802, pattern helpers :811-868, LZ4HC_countBack :202-225, price model :1778-1800,
+//      LZ4HC_encodeSequence :268-354.
 //
 // Parity first: this round the parser runs as ONE logical thread per block (all 64 lanes of the wave execute the same
 // scalar program on uniform data; loads broadcast, stores coalesce), with its 256 KiB hash/chain tables and the 64 KiB
@@ -85,18 +89,36 @@ DEV unsigned hc_rcount_pattern(const uint8_t* ip, const uint8_t* iLow, uint32_t 
     return (unsigned)(start - ip);
 }
 
-struct HcMatch { int len, off; };
+struct HcMatch { int len, off, back; };
 
-// LZ4HC_FindLongerMatch(ip, iHighLimit, minLen, nbSearches) == LZ4HC_InsertAndGetWiderMatch(ip, iLowLimit = ip, ..., patternAnalysis,
-// chainSwap) for a single prefix segment (lz4hc.c:1802-1820, :884-1104).
-DEV HcMatch hc_find_longer(HcState& s, int pos, int highLimit, int minLen, int nbSearches)
+// LZ4HC_countBack (lz4hc.c:202-225): common bytes before ip / match, as a value <= 0
+DEV int hc_count_back(const uint8_t* ip, const uint8_t* match, const uint8_t* iMin, const uint8_t* mMin)
+{
+    int back = 0;
+    const int a = (int)(iMin - ip), b = (int)(mMin - match);
+    const int mn = a > b ? a : b;
+    while (back - mn > 3) {
+        const uint32_t v = ld32u(ip + back - 4) ^ ld32u(match + back - 4);
+        if (v) return back - (int)(__builtin_clz(v) >> 3);
+        back -= 4;
+    }
+    while (back > mn && ip[back - 1] == match[back - 1]) back--;
+    return back;
+}
+
+// LZ4HC_InsertAndGetWiderMatch (lz4hc.c:884-1104) for a single prefix segment: `lowLimit` is iLowLimit (how far the match
+// may be extended backwards), `longest` the length to beat, patternAnalysis / chainSwap as in the reference.
+DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches,
+                          bool patternAnalysis, bool chainSwap)
 {
     const uint8_t* const src = s.src;
     const uint8_t* const ip = src + pos;
+    const uint8_t* const iLow = src + lowLimit;
     const uint8_t* const iHigh = src + highLimit;
     const uint32_t ipIndex = (uint32_t)pos + kHcBase;
     const uint32_t lowest = (kHcBase + 65536u > ipIndex) ? kHcBase : ipIndex - 65535u;          // :899-900
-    int longest = minLen, offset = 0;
+    const int lookBack = pos - lowLimit;
+    int offset = 0, sBack = 0;
     int attempts = nbSearches;
     uint32_t chainPos = 0;
     const uint32_t pattern = ld32u(ip);
@@ -111,14 +133,16 @@ DEV HcMatch hc_find_longer(HcState& s, int pos, int highLimit, int minLen, int n
         attempts--;
         {
             const uint8_t* const mp = src + (mi - kHcBase);
-            if (ld16u(ip + longest - 1) == ld16u(mp + longest - 1)) {                            // :929
+            if (ld16u(iLow + longest - 1) == ld16u(mp - lookBack + longest - 1)) {              // :929
                 if (ld32u(mp) == pattern) {
+                    const int back = lookBack ? hc_count_back(ip, mp, iLow, src) : 0;
                     mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
-                    if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); }
+                    mlen -= back;
+                    if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
                 }
             }
         }
-        if (mlen == longest) {                                                                   // chain swap, :964-987
+        if (chainSwap && mlen == longest) {                                                      // :964-987
             if (mi + (uint32_t)longest <= ipIndex) {
                 uint32_t distNext = 1;
                 const int end = longest - kMinMatch + 1;
@@ -137,7 +161,7 @@ DEV HcMatch hc_find_longer(HcState& s, int pos, int highLimit, int minLen, int n
         }
         {
             const uint32_t dn = s.w.chain[mi & 0xFFFFu];
-            if (dn == 1 && chainPos == 0) {                                                      // pattern analysis, :989-1062
+            if (patternAnalysis && dn == 1 && chainPos == 0) {                                   // :989-1062
                 const uint32_t mci = mi - 1;
                 if (repeat == 0) {
                     if (((pattern & 0xFFFFu) == (pattern >> 16)) & ((pattern & 0xFFu) == (pattern >> 24))) {
@@ -157,15 +181,17 @@ DEV HcMatch hc_find_longer(HcState& s, int pos, int highLimit, int minLen, int n
                             mi = mci + (uint32_t)fwd - (uint32_t)srcPatternLength;               // :1027-1036
                         } else {
                             mi = mci - (uint32_t)back;                                           // :1038-1058
-                            const size_t maxML = seg < srcPatternLength ? seg : srcPatternLength;
-                            if ((size_t)longest < maxML) {
-                                if (ipIndex - mi > 65535u) break;
-                                longest = (int)maxML;
-                                offset = (int)(ipIndex - mi);
+                            if (lookBack == 0) {
+                                const size_t maxML = seg < srcPatternLength ? seg : srcPatternLength;
+                                if ((size_t)longest < maxML) {
+                                    if (ipIndex - mi > 65535u) break;
+                                    longest = (int)maxML;
+                                    offset = (int)(ipIndex - mi);
+                                }
+                                const uint32_t dp = s.w.chain[mi & 0xFFFFu];
+                                if (dp > mi) break;
+                                mi -= dp;
                             }
-                            const uint32_t dp = s.w.chain[mi & 0xFFFFu];
-                            if (dp > mi) break;
-                            mi -= dp;
                         }
                         continue;
                     }
@@ -174,7 +200,14 @@ DEV HcMatch hc_find_longer(HcState& s, int pos, int highLimit, int minLen, int n
         }
         mi -= s.w.chain[(mi + chainPos) & 0xFFFFu];                                              // :1065
     }
-    HcMatch m; m.len = longest; m.off = offset;
+    HcMatch m; m.len = longest; m.off = offset; m.back = sBack;
+    return m;
+}
+
+// LZ4HC_FindLongerMatch (lz4hc.c:1802-1820): forward-only search with pattern analysis and chain swap
+DEV HcMatch hc_find_longer(HcState& s, int pos, int highLimit, int minLen, int nbSearches)
+{
+    HcMatch m = hc_find_wider(s, pos, pos, highLimit, minLen, nbSearches, true, true);
     if (m.len <= minLen) { m.len = 0; m.off = 0; }                                               // :1815
     return m;
 }
@@ -216,6 +249,190 @@ DEV bool hc_encode_seq(const uint8_t* src, int* ip, uint8_t* dst, int* op, int* 
     return false;
 }
 
+// Last literals of every HC strategy (lz4hc.c:1325-1352, :719-746), limitedOutput / notLimited only.  Returns the
+// compressed size, or 0 when the run does not fit.
+DEV int hc_last_literals(const uint8_t* src, int n, int anchor, uint8_t* dst, int op, bool limited, int oend)
+{
+    const int last = n - anchor;
+    const int llAdd = (last + 255 - 15) / 255;
+    if (limited && (int64_t)op + 1 + llAdd + last > oend) return 0;
+    if (last >= 15) {
+        int r = last - 15;
+        dst[op++] = 0xF0;
+        for (; r >= 255; r -= 255) dst[op++] = 255;
+        dst[op++] = (uint8_t)r;
+    } else dst[op++] = (uint8_t)(last << 4);
+    for (int i = 0; i < last; ++i) dst[op + i] = src[anchor + i];
+    return op + last;
+}
+
+DEV void hc_reset_tables(HcWork w)
+{
+    // LZ4_initStreamHC zeroes the whole state (hash AND chain), lz4hc.c:1582-1583
+    for (int i = 0; i < kHcHashEntries; ++i) w.hash[i] = 0;
+    for (int i = 0; i < kHcChainEntries; ++i) w.chain[i] = 0;
+}
+
+// Levels 3..9: LZ4HC_compress_hashChain (lz4hc.c:1121-1363), nbSearches = 1 << (level - 1) (table :92-106),
+// patternAnalysis only above 128 attempts (level 9).  The goto structure of the reference is kept: it IS the algorithm.
+DEV int hc_compress_chain(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w)
+{
+    if ((uint32_t)n > (uint32_t)kMaxInput) return 0;                                             // :1388
+    const bool limited = cap < compress_bound(n);
+    const int  maxNb = 1 << (level - 1);
+    const bool pa = maxNb > 128;
+    hc_reset_tables(w);
+    HcState s; s.src = src; s.n = n; s.w = w; s.nextToUpdate = kHcBase;
+
+    int ip = 0, anchor = 0, op = 0;
+    const int oend = cap;
+    const int mflimit = n - kMfLimit;
+    const int matchlimit = n - kLastLiterals;
+    const int kOptimalMl = 15 - 1 + kMinMatch;                                                   // OPTIMAL_ML, lz4hc.c:75
+    int start0 = 0, start2 = 0, start3 = 0;
+    HcMatch m0 = {0, 0, 0}, m1 = {0, 0, 0}, m2 = {0, 0, 0}, m3 = {0, 0, 0};
+
+    if (n < kMinLength) goto last_literals;                                                      // :1155
+    while (ip <= mflimit) {
+        m1 = hc_find_wider(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, pa, false);              // :1159
+        if (m1.len < kMinMatch) { ip++; continue; }
+        start0 = ip; m0 = m1;
+search2:
+        if (ip + m1.len <= mflimit) {                                                            // :1167-1175
+            start2 = ip + m1.len - 2;
+            m2 = hc_find_wider(s, start2, ip, matchlimit, m1.len, maxNb, pa, false);
+            start2 += m2.back;
+        } else { m2.len = 0; m2.off = 0; m2.back = 0; }
+        if (m2.len <= m1.len) {                                                                  // :1177-1184
+            if (hc_encode_seq(src, &ip, dst, &op, &anchor, m1.len, m1.off, limited, oend)) return 0;
+            continue;
+        }
+        if (start0 < ip) {                                                                       // :1186-1189
+            if (start2 < ip + m0.len) { ip = start0; m1 = m0; }
+        }
+        if (start2 - ip < 3) { ip = start2; m1 = m2; goto search2; }                             // :1192-1196
+search3:
+        if (start2 - ip < kOptimalMl) {                                                          // :1199-1210
+            int new_ml = m1.len;
+            if (new_ml > kOptimalMl) new_ml = kOptimalMl;
+            if (ip + new_ml > start2 + m2.len - kMinMatch) new_ml = (start2 - ip) + m2.len - kMinMatch;
+            const int correction = new_ml - (start2 - ip);
+            if (correction > 0) { start2 += correction; m2.len -= correction; }
+        }
+        if (start2 + m2.len <= mflimit) {                                                        // :1212-1220
+            start3 = start2 + m2.len - 3;
+            m3 = hc_find_wider(s, start3, start2, matchlimit, m2.len, maxNb, pa, false);
+            start3 += m3.back;
+        } else { m3.len = 0; m3.off = 0; m3.back = 0; }
+        if (m3.len <= m2.len) {                                                                  // :1222-1240
+            if (start2 < ip + m1.len) m1.len = start2 - ip;
+            if (hc_encode_seq(src, &ip, dst, &op, &anchor, m1.len, m1.off, limited, oend)) return 0;
+            ip = start2;
+            if (hc_encode_seq(src, &ip, dst, &op, &anchor, m2.len, m2.off, limited, oend)) return 0;
+            continue;
+        }
+        if (start3 < ip + m1.len + 3) {                                                          // :1242-1270
+            if (start3 >= ip + m1.len) {
+                if (start2 < ip + m1.len) {
+                    const int correction = ip + m1.len - start2;
+                    start2 += correction;
+                    m2.len -= correction;
+                    if (m2.len < kMinMatch) { start2 = start3; m2 = m3; }
+                }
+                if (hc_encode_seq(src, &ip, dst, &op, &anchor, m1.len, m1.off, limited, oend)) return 0;
+                ip = start3; m1 = m3;
+                start0 = start2; m0 = m2;
+                goto search2;
+            }
+            start2 = start3; m2 = m3;
+            goto search3;
+        }
+        if (start2 < ip + m1.len) {                                                              // :1277-1291
+            if (start2 - ip < kOptimalMl) {
+                if (m1.len > kOptimalMl) m1.len = kOptimalMl;
+                if (ip + m1.len > start2 + m2.len - kMinMatch) m1.len = (start2 - ip) + m2.len - kMinMatch;
+                const int correction = m1.len - (start2 - ip);
+                if (correction > 0) { start2 += correction; m2.len -= correction; }
+            } else m1.len = start2 - ip;
+        }
+        if (hc_encode_seq(src, &ip, dst, &op, &anchor, m1.len, m1.off, limited, oend)) return 0;
+        ip = start2; m1 = m2;                                                                    // :1299-1306
+        start2 = start3; m2 = m3;
+        goto search3;
+    }
+last_literals:
+    return hc_last_literals(src, n, anchor, dst, op, limited, oend);
+}
+
+// Level 2: LZ4MID_compress (lz4hc.c:521-775).  Two 16 K-entry tables inside the HC hash table: 4-byte hashes in the lower
+// half, 7-of-8-byte hashes in the upper half (:141-151, :532-533).
+DEV uint32_t mid_hash4(const uint8_t* p) { return (ld32u(p) * 2654435761u) >> (32 - 14); }
+DEV uint32_t mid_hash8(const uint8_t* p) { return (uint32_t)(((ld64u(p) << 8) * 58295818150454627ull) >> (64 - 14)); }
+
+DEV int hc_compress_mid(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap, HcWork w)
+{
+    if ((uint32_t)n > (uint32_t)kMaxInput) return 0;
+    const bool limited = cap < compress_bound(n);
+    hc_reset_tables(w);
+    uint32_t* const h4t = w.hash;
+    uint32_t* const h8t = w.hash + 16384;
+    int ip = 0, anchor = 0, op = 0;
+    const int oend = cap;
+    const int mflimit = n - kMfLimit;
+    const int matchlimit = n - kLastLiterals;
+    const uint32_t ilimitIdx = (uint32_t)(n - 8) + kHcBase;
+    const uint8_t* const mlim = src + matchlimit;
+
+    if (n >= kMinLength) while (ip <= mflimit) {
+        const uint32_t ipIndex = (uint32_t)ip + kHcBase;
+        int ml = 0; uint32_t dist = 0;
+        {   // long match (:572-601); candidates below the prefix start do not exist for an independent block
+            const uint32_t h8 = mid_hash8(src + ip);
+            const uint32_t pos8 = h8t[h8];
+            h8t[h8] = ipIndex;
+            if (ipIndex - pos8 <= 65535u && pos8 >= kHcBase) {
+                ml = hc_count(src + ip, src + (pos8 - kHcBase), mlim);
+                if (ml >= kMinMatch) dist = ipIndex - pos8; else ml = 0;
+            }
+        }
+        if (!ml) {   // short match, then one look at ip+1 for a longer one (:603-650)
+            const uint32_t h4 = mid_hash4(src + ip);
+            const uint32_t pos4 = h4t[h4];
+            h4t[h4] = ipIndex;
+            if (ipIndex - pos4 <= 65535u && pos4 >= kHcBase) {
+                ml = hc_count(src + ip, src + (pos4 - kHcBase), mlim);
+                if (ml >= kMinMatch) {
+                    const uint32_t h8 = mid_hash8(src + ip + 1);
+                    const uint32_t pos8 = h8t[h8];
+                    const uint32_t m2d = ipIndex + 1 - pos8;
+                    dist = ipIndex - pos4;
+                    if (m2d <= 65535u && pos8 >= kHcBase && ip < mflimit) {
+                        const int ml2 = hc_count(src + ip + 1, src + (pos8 - kHcBase), mlim);
+                        if (ml2 > ml) { h8t[h8] = ipIndex + 1; ip++; ml = ml2; dist = m2d; }
+                    }
+                } else ml = 0;
+            }
+        }
+        if (!ml) { ip += 1 + ((ip - anchor) >> 9); continue; }                                   // :668
+        while (ip > anchor && (uint32_t)ip > dist && src[ip - 1] == src[ip - (int)dist - 1]) { ip--; ml++; }   // :673-675
+        // "fill table with beginning of match": the index stays the loop-top ipIndex although ip may have moved (:678-680)
+        h8t[mid_hash8(src + ip + 1)] = ipIndex + 1;
+        h8t[mid_hash8(src + ip + 2)] = ipIndex + 2;
+        h4t[mid_hash4(src + ip + 1)] = ipIndex + 1;
+        if (hc_encode_seq(src, &ip, dst, &op, &anchor, ml, (int)dist, limited, oend)) return 0;
+        {   const uint32_t endIdx = (uint32_t)ip + kHcBase;                                      // :695-706
+            if (endIdx - 2 < ilimitIdx) {
+                if (ip > 5) h8t[mid_hash8(src + ip - 5)] = endIdx - 5;
+                h8t[mid_hash8(src + ip - 3)] = endIdx - 3;
+                h8t[mid_hash8(src + ip - 2)] = endIdx - 2;
+                h4t[mid_hash4(src + ip - 2)] = endIdx - 2;
+                h4t[mid_hash4(src + ip - 1)] = endIdx - 1;
+            }
+        }
+    }
+    return hc_last_literals(src, n, anchor, dst, op, limited, oend);
+}
+
 // Level table rows 10..12 (lz4hc.c:92-106): {nbSearches, targetLength}; fullUpdate only at level 12 (:1406).
 DEV int hc_compress_opt(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w)
 {
@@ -227,9 +444,7 @@ DEV int hc_compress_opt(const uint8_t* __restrict__ src, const int n, uint8_t* _
     if (sufficient >= (size_t)kHcOptNum) sufficient = kHcOptNum - 1;                             // :1860
     HcOpt* const opt = w.opt;
 
-    // LZ4_initStreamHC zeroes the whole state (hash AND chain), lz4hc.c:1582-1583
-    for (int i = 0; i < kHcHashEntries; ++i) w.hash[i] = 0;
-    for (int i = 0; i < kHcChainEntries; ++i) w.chain[i] = 0;
+    hc_reset_tables(w);
     HcState s; s.src = src; s.n = n; s.w = w; s.nextToUpdate = kHcBase;
 
     int ip = 0, anchor = 0, op = 0;
@@ -319,20 +534,18 @@ DEV int hc_compress_opt(const uint8_t* __restrict__ src, const int n, uint8_t* _
             }
         }
     }
-    {   // last literals (:2067-2098), limitedOutput / notLimited only
-        const int last = n - anchor;
-        const int llAdd = (last + 255 - 15) / 255;
-        if (limited && (int64_t)op + 1 + llAdd + last > oend) return 0;
-        if (last >= 15) {
-            int r = last - 15;
-            dst[op++] = 0xF0;
-            for (; r >= 255; r -= 255) dst[op++] = 255;
-            dst[op++] = (uint8_t)r;
-        } else dst[op++] = (uint8_t)(last << 4);
-        for (int i = 0; i < last; ++i) dst[op + i] = src[anchor + i];
-        op += last;
-    }
-    return op;
+    return hc_last_literals(src, n, anchor, dst, op, limited, oend);                             // :2067-2098
 }
+
+// LZ4_compress_HC(level) for every level plz4 routes to the HC entry point (2..12); LZ4HC_getCLevelParams, lz4hc.c:108-117
+DEV int hc_compress(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap, int level, HcWork w)
+{
+    if (level < 1) level = 9;
+    if (level > 12) level = 12;
+    if (level <= 2) return hc_compress_mid(src, n, dst, cap, w);
+    if (level <= 9) return hc_compress_chain(src, n, dst, cap, level, w);
+    return hc_compress_opt(src, n, dst, cap, level, w);
+}
+
 
 }  // namespace plz4

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64) void k_encode_raw_hc(CodecArgs a)
     const HcWork w = hc_work_of(a);
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
         const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
-        const int r = hc_compress_opt(a.src + (int64_t)i * a.srcStride, block_len(a, i), a.dst + (int64_t)i * a.dstStride, cap, a.level, w);
+        const int r = hc_compress(a.src + (int64_t)i * a.srcStride, block_len(a, i), a.dst + (int64_t)i * a.dstStride, cap, a.level, w);
         if ((threadIdx.x & 63u) == 0) a.result[i] = r;
     }
 }
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
         const int      n   = block_len(a, i);
         const uint8_t* s   = a.src + (int64_t)i * a.srcStride;
         uint8_t*       rec = a.dst + (int64_t)i * a.dstStride;
-        int      c    = hc_compress_opt(s, n, rec + 4, a.bsz, a.level, w);   // capacity == bsz (blk.go:73); indie.go:80-88
+        int      c    = hc_compress(s, n, rec + 4, a.bsz, a.level, w);   // capacity == bsz (blk.go:73); indie.go:80-88
         uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
         WAVE_FENCE();
         if (c == 0) { wave_copy(rec + 4, s, n); c = n; word = 0x80000000u | ((uint32_t)n & 0x7FFFFFFFu); }
@@ -444,7 +444,7 @@ int ensure_staging(plz4hip_ctx* c, size_t hostBytes, size_t devBytes)
 
 int grid_for(int nBlocks, int resident) { return nBlocks < resident ? nBlocks : resident; }
 
-bool is_hc_level(int level) { return level >= 10 && level <= 12; }      // lz4opt rows of the level table (lz4hc.c:92-106)
+bool is_hc_level(int level) { return level >= 2 && level <= 12; }        // every row of the level table (lz4hc.c:92-106): mid, hash chain, optimal
 
 int ensure_hc(plz4hip_ctx* c)
 {

@@ -1,0 +1,54 @@
+"""One-off fuzz: the device HC source (compiled for the CPU by tests/emu) against the real LZ4_compress_HC in oracle/_ref,
+levels 2..12, three capacities per input.  Not part of the test-suite (takes minutes); run from the repo root."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import corpus                      # noqa: E402
+from emulib import Emu             # noqa: E402
+from orclib import Oracle, Ref     # noqa: E402
+from plz4_amd import synth         # noqa: E402
+
+
+def main(iters=400, seed=7):
+    emu, ref, orc = Emu(), Ref(), Oracle()
+    rng = np.random.default_rng(seed)
+    bad = tot = 0
+    for it in range(iters):
+        n = int(rng.integers(0, 60000))
+        kind = it % 5
+        if kind == 0:
+            src = corpus.structured(n, it)
+        elif kind == 1:                                  # runs of short repeated patterns (pattern analysis, level >= 9)
+            parts, have = [], 0
+            while have < n:
+                pat = rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8)
+                parts += [np.tile(pat, int(rng.integers(1, 3000))), rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8)]
+                have += parts[-1].size + parts[-2].size
+            src = np.concatenate(parts)[:n].copy() if parts else np.zeros(0, np.uint8)
+        elif kind == 2:
+            src = rng.integers(0, 4, n, dtype=np.uint8)
+        elif kind == 3:
+            src = synth.text(n + 1)[:n].copy()
+        else:
+            base = rng.integers(0, 256, max(n // 7, 1), dtype=np.uint8)
+            src = np.tile(base, 8)[:n].copy()
+            if n:
+                src[rng.integers(0, n, n // 50)] = 0
+        for lvl in range(2, 13):
+            for cap in (orc.bound(src.size), src.size, max(src.size // 2, 1)):
+                a, da = ref.compress_hc(src, cap, lvl)
+                b, db = emu.compress_hc(src, cap, lvl)
+                tot += 1
+                if a != b or not np.array_equal(da, db):
+                    bad += 1
+                    print("MISMATCH", it, kind, n, lvl, cap, a, b)
+    print("total", tot, "bad", bad)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(*(int(x) for x in sys.argv[1:])) else 0)

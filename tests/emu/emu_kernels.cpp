@@ -32,7 +32,7 @@ int emu_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level)
     plz4::HcWork w;
     w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + plz4::kHcHashEntries * 4);
     w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2);
-    return plz4::hc_compress_opt(src, n, dst, cap, level, w);
+    return plz4::hc_compress(src, n, dst, cap, level, w);
 }
 
 int emu_encode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, const uint8_t* dict, int dictSize, int mode,

@@ -70,9 +70,10 @@ def main():
             blocks.append({"kind": kind, "bsz": bsz, "index": i, "src_sha": sha(blk), "ret": r, "comp_sha": sha(c) if r else None})
     json.dump({"reference": "liblz4 1.10.0", "blocks": blocks}, open(os.path.join(HERE, "block_digests.json"), "w"), indent=0)
 
-    # ---- HC optimal-parser levels (config 4 = level 12): LZ4_compress_HC of the real reference
+    # ---- HC levels 2..12 (config 4 = level 12): LZ4_compress_HC of the real reference
     hc = []
-    for kind, bsz, nblk, levels in (("T", 64 << 10, 4, (10, 11, 12)), ("M", 256 << 10, 3, (10, 11, 12)), ("T", 4 << 20, 1, (12,))):
+    ALL = tuple(range(2, 13))
+    for kind, bsz, nblk, levels in (("T", 64 << 10, 4, ALL), ("M", 256 << 10, 3, ALL), ("T", 4 << 20, 1, (2, 5, 9, 12))):
         data = synth.make(kind, nblk * bsz, bsz)
         for i in range(nblk):
             blk = data[i * bsz:(i + 1) * bsz]

@@ -1,4 +1,4 @@
-"""HC optimal-parser levels 10..12 (BASELINE config 4 = level 12).  The restatement is the device source itself
+"""HC levels 2..12: lz4mid (2), hash chain (3..9), optimal parser (10..12; BASELINE config 4 = level 12).  The restatement is the device source itself
 (plz4_amd/csrc/lz4hc_device.inl): on CPU it is compiled by the emulation harness and checked against the REAL reference
 (oracle/_ref, LZ4_compress_HC) and the committed digests; on the GPU (-m gpu) the same checks run through the C ABI."""
 import hashlib
@@ -11,6 +11,7 @@ import pytest
 import corpus
 from plz4_amd import synth
 
+LEVELS = tuple(range(2, 13))
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
@@ -48,7 +49,7 @@ def emu():
 
 def test_emu_hc_vs_reference(ref, orc, emu):
     for name, src in _cases():
-        for lvl in (10, 11, 12):
+        for lvl in LEVELS:
             for cap in (orc.bound(src.size), src.size, max(src.size // 3, 1)):
                 a, da = ref.compress_hc(src, cap, lvl)
                 b, db = emu.compress_hc(src, cap, lvl)
@@ -69,7 +70,7 @@ def test_gpu_hc_vs_reference(ref, orc):
     from plz4_amd._native import Engine
     eng = Engine(0)
     cases = [c for c in _cases() if c[1].size <= 150000]
-    for lvl in (10, 11, 12):
+    for lvl in LEVELS:
         srcs = [s for _, s in cases]
         for capf in (lambda n: orc.bound(n), lambda n: n):
             caps = [capf(s.size) for s in srcs]
@@ -86,7 +87,7 @@ def test_gpu_hc_golden_and_frame(orc):
     from plz4_amd._native import Engine
     eng = Engine(0)
     items = [(b, blk) for b, blk in _golden_blocks() if b["bsz"] <= (256 << 10)]
-    for lvl in (10, 11, 12):
+    for lvl in LEVELS:
         for bsz in sorted({b["bsz"] for b, _ in items}):
             sel = [(b, blk) for b, blk in items if b["bsz"] == bsz and b["level"] == lvl]
             recs = eng.encode_records([blk for _, blk in sel], bsz, True, level=lvl)
