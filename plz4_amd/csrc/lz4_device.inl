@@ -308,6 +308,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                 if (base >= 64 && base + 96 <= n) {
                     uint32_t* T = (uint32_t*)tab;
                     STAT(S_GRID, 1);
+                    const unsigned long long tg0 = STAT_NOW(); (void)tg0;
                     LV(int, act); LV(uint32_t, h); LV(uint32_t, r); LV(uint32_t, lit8);
                     LV(uint32_t, ent); LV(uint32_t, rent);           // my table entry / the entry I displaced
                     LV(int, hit); LV(int, fwd); LV(int, bck); LV(int, eLane);
@@ -351,6 +352,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                     }
                     {
                         uint64_t hits  = BALLOT(hit[I_]);
+                        const unsigned long long tg1 = STAT_NOW(); (void)tg1;
+                        STAT(S_CYC_LOAD, tg1 - tg0);
                         uint64_t twins = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);          // earlier twin inside this batch
                         const uint64_t anyTwins = twins;                                          // (bits of repaired lanes get cleared below)
                         uint64_t specialLeft = BALLOT(hit[I_] && fwd[I_] == 16);           // longer than the speculative window: the hop needs its end
@@ -454,6 +457,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             }
                             break;
                         }
+                        const unsigned long long tg2 = STAT_NOW(); (void)tg2;
+                        STAT(S_CYC_WALK, tg2 - tg1);
                         STAT(S_SEQ_GRID, __builtin_popcountll(mm));
                         STAT(S_LANES_EXEC, __builtin_popcountll(E));
 
@@ -528,6 +533,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             }
                             anchor = base + eL;
                         }
+                        const unsigned long long tg3 = STAT_NOW(); (void)tg3;
+                        STAT(S_CYC_SAT, tg3 - tg2);
                         if (finished) break;
 
                         // ---- 5. parser state after this batch
@@ -548,6 +555,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         LANES({ if (act[I_] && !((EL2 >> LANE) & 1)) lds_min(&T[h[I_]], rent[I_]); })
                         if (anyTwins) { LDS_FENCE(); LANES({ if ((EL2 >> LANE) & 1) lds_max(&T[h[I_]], ent[I_]); }) }
                         LDS_FENCE();
+                        STAT(S_CYC_FIX, STAT_NOW() - tg3);
                         width = 64;
                         continue;
                     }
@@ -950,26 +958,34 @@ DEV int64_t read_more_len(const uint8_t* src, int* ip, int ilimit, bool initialC
 }
 
 // Vector fast path of the decoder: 64 lanes look at the next 64 input bytes, each as if a sequence started at its
-// byte; a scalar hop follows the real token chain through the window while the sequences are "plain" (literal
-// run < 15, match length nibble < 15, literals inside the window, offset >= match length); output positions come
-// from a wave prefix sum; a plain sequence is kept only if its match source lies entirely before this batch's
-// output (so every copy of the batch is independent and issued together).  Everything else -- long lengths,
-// overlapping or near matches, bad offsets, the ends of the block -- is left to the exact sequential step of
+// byte (it holds the 16 bytes from there on, so token, literals and offset of a short sequence are in registers);
+// a scalar hop follows the real token chain through the window while the sequences are "plain" (literal run < 14,
+// match length nibble < 15, literals inside the window, offset >= match length); output positions come from a
+// wave prefix sum on the DPP network; matches whose source lies before this batch's output are copied together, the
+// others ("near": the source holds bytes of this very batch) follow in rounds of mutually independent copies.
+// Everything else -- long lengths, overlapping matches, bad offsets, the ends of the block -- is left to the exact sequential step of
 // wave_decode_block, which also owns liblz4's accept/reject rules.  Returns the number of sequences decoded.
 // Caller guarantees ip0 + 160 <= iend and op0 + 1088 <= oend (the reference is in its fast loop there).
-DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int* ipp, int64_t* opp)
+DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int* ipp, int64_t* opp,
+                                LVREF(v16u_t, win), int* winIp)
 {
     const int ip0 = *ipp; const int64_t op0 = *opp;
+    // every lane holds the 16 input bytes from its window position on; normally requested by the previous batch
+    if (*winIp != ip0) { LANES({ win[I_] = *(const v16u_t*)(src + ip0 + LANE); }) }
     LV(uint32_t, b0); LV(int, ll); LV(int, ml); LV(int, off); LV(int, nxt); LV(int, outLen); LV(int, plain);
     LANES({
-        const uint64_t w = ld64u(src + ip0 + LANE);
-        const uint32_t t = (uint32_t)(w & 0xFF);
+        const uint64_t w0 = (uint64_t)win[I_].w[0] | ((uint64_t)win[I_].w[1] << 32);
+        const uint64_t w1 = (uint64_t)win[I_].w[2] | ((uint64_t)win[I_].w[3] << 32);
+        const uint32_t t = (uint32_t)(w0 & 0xFF);
         const int l = (int)(t >> 4), mn = (int)(t & 15);
         const int offAt = LANE + 1 + l;                      // window index of the offset's low byte
-        const uint32_t o16 = (l <= 5) ? (uint32_t)((w >> (8 * (1 + l))) & 0xFFFF) : (uint32_t)ld16u(src + ip0 + offAt);
+        // the offset sits at bytes 1+l, 2+l of the lane's 16: pick the 8-byte word that holds both (l <= 13)
+        const uint64_t sel = (l <= 5) ? w0 : (l <= 9 ? ((w0 >> 32) | (w1 << 32)) : w1);
+        const int      sft = 8 * (1 + l - (l <= 5 ? 0 : (l <= 9 ? 4 : 8)));
+        const uint32_t o16 = (uint32_t)((sel >> sft) & 0xFFFF);
         b0[I_] = t; ll[I_] = l; ml[I_] = mn + kMinMatch; off[I_] = (int)o16;
         nxt[I_] = offAt + 2; outLen[I_] = l + mn + kMinMatch;
-        plain[I_] = (l < 15) && (mn < 15) && (offAt <= 64) && (o16 >= (uint32_t)(mn + kMinMatch));
+        plain[I_] = (l < 14) && (mn < 15) && (offAt <= 64) && (o16 >= (uint32_t)(mn + kMinMatch));
     })
     const uint64_t plainMask = BALLOT(plain[I_]);
     uint64_t members = 0;
@@ -977,39 +993,48 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
     if (!members) return 0;
 
     // exclusive prefix sum of the members' output lengths -> where each sequence writes
-    LV(int, acc); LV(int, tmp); LV(int, outStart);
+    LV(int, acc); LV(int, outStart); LV(int, sp);
     { const uint64_t mL = members; LANES({ acc[I_] = ((mL >> LANE) & 1) ? outLen[I_] : 0; }) }
-    for (int d = 1; d < 64; d <<= 1) {
-        LANES({ tmp[I_] = SHFL(acc, LANE >= d ? LANE - d : LANE); })
-        LANES({ if (LANE >= d) acc[I_] += tmp[I_]; })
-    }
+    SCAN_INCL(acc);
     {
         const uint64_t mL = members;
-        LANES({ outStart[I_] = (int)op0 + acc[I_] - (((mL >> LANE) & 1) ? outLen[I_] : 0); })
-        // keep the prefix of sequences whose match source is valid and entirely older than this batch
-        const uint64_t bad = BALLOT(((mL >> LANE) & 1) &&
-                                    (outStart[I_] + ll[I_] - off[I_] < 0 || (int64_t)outStart[I_] + ll[I_] - off[I_] + ml[I_] > op0));
-        if (bad) members &= (1ull << ctz64(bad)) - 1;
+        LANES({
+            outStart[I_] = (int)op0 + acc[I_] - (((mL >> LANE) & 1) ? outLen[I_] : 0);
+            sp[I_]       = outStart[I_] + ll[I_] - off[I_];                     // where the match bytes come from
+        })
+        // a source before the start of the output is the sequential step's business (error, or a dictionary)
+        const uint64_t neg = BALLOT(((mL >> LANE) & 1) && sp[I_] < 0);
+        if (neg) members &= (1ull << ctz64(neg)) - 1;
     }
     if (!members) return 0;
     const uint64_t mL = members;
-    // match bytes: every member lane copies its own 4..18 bytes (loads first, they never depend on this batch)
-    LANES({
-        if ((mL >> LANE) & 1) {
-            const uint8_t* s = dst + outStart[I_] + ll[I_] - off[I_];
-            uint8_t*       d = dst + outStart[I_] + ll[I_];
-            const v16u_t a = *(const v16u_t*)s;
-            const uint32_t b = ld16u(s + 16);
-            const uint64_t lo = (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), hi = (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32);
-            int rem = ml[I_]; uint64_t cur;
-            if (rem >= 16)     { *(v16u_t*)d = a; d += 16; rem -= 16; cur = b; }
-            else if (rem >= 8) { st64u(d, lo); d += 8; rem -= 8; cur = hi; }
-            else cur = lo;
-            if (rem & 4) { st32u(d, (uint32_t)cur); d += 4; cur >>= 32; }
-            if (rem & 2) { st16u(d, (uint16_t)cur); d += 2; cur >>= 16; }
-            if (rem & 1) { *d = (uint8_t)cur; }
-        }
-    })
+    const int last = 63 - __builtin_clzll(members);
+    const int ipn  = ip0 + RL(nxt, last);
+    // request the next batch's window now: its latency hides behind this batch's copies (ipn + 63 + 16 < ip0 + 160 <= iend)
+    LANES({ win[I_] = *(const v16u_t*)(src + ipn + LANE); })
+    *winIp = ipn;
+    // Match bytes, 4..18 per member lane.  "Far" sources end before this batch's output: all of them are copied at once.
+    // A "near" source may contain bytes this batch produces; those go in dependency order below.
+    const uint64_t far = mL & BALLOT((int64_t)sp[I_] + ml[I_] <= op0);
+    auto copy_matches = [&](const uint64_t who) {
+        LANES({
+            if ((who >> LANE) & 1) {
+                const uint8_t* s = dst + sp[I_];
+                uint8_t*       d = dst + outStart[I_] + ll[I_];
+                const v16u_t a = *(const v16u_t*)s;
+                const uint32_t b = ld16u(s + 16);
+                const uint64_t lo = (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), hi = (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32);
+                int rem = ml[I_]; uint64_t cur;
+                if (rem >= 16)     { *(v16u_t*)d = a; d += 16; rem -= 16; cur = b; }
+                else if (rem >= 8) { st64u(d, lo); d += 8; rem -= 8; cur = hi; }
+                else cur = lo;
+                if (rem & 4) { st32u(d, (uint32_t)cur); d += 4; cur >>= 32; }
+                if (rem & 2) { st16u(d, (uint16_t)cur); d += 2; cur >>= 16; }
+                if (rem & 1) { *d = (uint8_t)cur; }
+            }
+        })
+    };
+    copy_matches(far);
     // literal bytes: every window byte finds the member it follows
     LANES({
         const uint64_t upto = mL & ((LANE >= 63) ? ~0ull : ((2ull << LANE) - 1));
@@ -1017,8 +1042,17 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         const int os = SHFL(outStart, m), lm = SHFL(ll, m);
         if (upto && LANE > m && LANE <= m + lm) dst[os + (LANE - m - 1)] = (uint8_t)b0[I_];
     })
-    const int last = 63 - __builtin_clzll(members);
-    *ipp = ip0 + RL(nxt, last);
+    // near matches: each round takes every pending one whose source ends before the first pending match's output
+    // (the first one always qualifies: offset >= length), so nothing it reads is still to be written
+    for (uint64_t pend = mL & ~far; pend; ) {
+        const int f  = ctz64(pend);
+        const int lo = RL(outStart, f) + RL(ll, f);
+        const uint64_t go = pend & BALLOT(sp[I_] + ml[I_] <= lo);
+        WAVE_FENCE();
+        copy_matches(go);
+        pend &= ~go;
+    }
+    *ipp = ipn;
     *opp = (int64_t)RL(outStart, last) + RL(outLen, last);
     return __builtin_popcountll(members);
 }
@@ -1042,12 +1076,14 @@ DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t*
     if (cap == 0) return (n == 1 && UNI(src[0]) == 0) ? 0 : -1;
     if (n == 0) return -1;
     bool fast = (oend - op) >= 64;
+    LV(v16u_t, win); int winIp = -1;              // the vector path's input window, requested one batch ahead
+    LANES({ win[I_].w[0] = 0; win[I_].w[1] = 0; win[I_].w[2] = 0; win[I_].w[3] = 0; })
     STAT_DECL;
 
     for (;;) {
         if (fast && ip + 160 <= iend && op + 1088 <= oend) {
             WAVE_FENCE();
-            const int nm = wave_decode_plain_batch(src, dst, &ip, &op);
+            const int nm = wave_decode_plain_batch(src, dst, &ip, &op, win, &winIp);
             STAT(S_DBATCH, 1); STAT(S_DMEMB, nm);
             if (nm > 0) { WAVE_FENCE(); continue; }
         }

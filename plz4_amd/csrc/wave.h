@@ -32,6 +32,8 @@
 #define WL(x, w, v)    do { const auto wl_v_ = (v); (x)[(w)] = wl_v_; } while (0)   /* write one lane (uniform lane index) */
 #define SHFL(x, l)     ((x)[(l) & 63])                  /* read another lane's value (per-lane lane index) */
 #define UNI(x)         (x)
+#define LVREF(T, x)    T (&x)[64]                       /* a per-lane variable as a function parameter */
+#define SCAN_INCL(x)   do { for (int s_ = 1; s_ < 64; ++s_) (x)[s_] += (x)[s_ - 1]; } while (0)   /* inclusive prefix sum over lanes */
 #define WAVE_FENCE()   do {} while (0)
 #define LDS_FENCE()    do {} while (0)
 // Same-address LDS store conflicts inside one instruction are resolved in an unspecified lane order on
@@ -55,6 +57,8 @@ static inline int plz4_emu_step()  { return plz4_emu_descending ? -1 : 1; }
 #define WL(x, w, v)    do { const auto wl_v_ = (v); (x)[0] = (LANE == (w)) ? wl_v_ : (x)[0]; } while (0)
 #define SHFL(x, l)     plz4_bpermute((x)[0], (l))
 #define UNI(x)         plz4_readfirstlane((x))
+#define LVREF(T, x)    T (&x)[1]
+#define SCAN_INCL(x)   do { (x)[0] = plz4_scan_incl((x)[0]); } while (0)
 // Same-wave producer/consumer through memory needs no cache action on CDNA (one TCP, in-order VMEM
 // queue); the fence only stops the compiler from reordering the accesses.
 #define WAVE_FENCE()   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
@@ -67,6 +71,18 @@ __device__ __forceinline__ uint64_t plz4_readlane(uint64_t v, int l)
     uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
     return ((uint64_t)hi << 32) | lo;
+}
+// Inclusive prefix sum over the 64 lanes on the DPP network (no LDS round trips): log steps inside each row of 16,
+// then row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3.  All 64 lanes must be active.
+__device__ __forceinline__ int plz4_scan_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast31 -> rows 2, 3
+    return v;
 }
 __device__ __forceinline__ int      plz4_bpermute(int v, int l)      { return __builtin_amdgcn_ds_bpermute(l << 2, v); }
 __device__ __forceinline__ uint32_t plz4_bpermute(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_ds_bpermute(l << 2, (int)v); }

@@ -40,11 +40,9 @@ for chk in (True, False):
     for k in names:
         print("   %-10s %14d   per block %12.1f" % (k, v[k], v[k] / nb))
     g = max(v["grid"], 1)
-    print("   per grid batch: load %.0f cyc, walk %.0f cyc, fix %.0f cyc, seqs %.2f, lanes exec %.1f, walk iters %.2f"
-          % (v["cyc_load"] / g, v["cyc_walk"] / g, v["cyc_fix"] / g, v["seq_grid"] / g, v["lanes_exec"] / g, v["walkiter"] / g))
-    print("   per generic batch: %.0f cyc;  sat: %.0f cyc each; memlit: %.0f cyc each; total cyc/block %.3e"
-          % (v["cyc_gen"] / max(v["generic"], 1), v["cyc_sat"] / max(v["sat"], 1), v["cyc_memlit"] / max(v["memlit"], 1),
-             v["cyc_total"] / nb))
+    print("   per grid batch: phase1 %.0f cyc, hop %.0f cyc, emit %.0f cyc, fix %.0f cyc, seqs %.2f, lanes exec %.1f, walk iters %.2f"
+          % (v["cyc_load"] / g, v["cyc_walk"] / g, v["cyc_sat"] / g, v["cyc_fix"] / g, v["seq_grid"] / g, v["lanes_exec"] / g, v["walkiter"] / g))
+    print("   per generic batch: %.0f cyc;  total cyc/block %.3e" % (v["cyc_gen"] / max(v["generic"], 1), v["cyc_total"] / nb))
 
 # decode stats
 d_off = torch.zeros(B + 1, dtype=torch.int64, device=dev)
