@@ -960,10 +960,11 @@ DEV int64_t read_more_len(const uint8_t* src, int* ip, int ilimit, bool initialC
 // Vector fast path of the decoder: 64 lanes look at the next 64 input bytes, each as if a sequence started at its
 // byte (it holds the 16 bytes from there on, so token, literals and offset of a short sequence are in registers);
 // a scalar hop follows the real token chain through the window while the sequences are "plain" (literal run < 14,
-// match length nibble < 15, literals inside the window, offset >= match length); output positions come from a
+// literals inside the window, match length in the nibble or in one extension byte); output positions come from a
 // wave prefix sum on the DPP network; matches whose source lies before this batch's output are copied together, the
-// others ("near": the source holds bytes of this very batch) follow in rounds of mutually independent copies.
-// Everything else -- long lengths, overlapping matches, bad offsets, the ends of the block -- is left to the exact sequential step of
+// others ("near": the source holds bytes of this very batch) follow in rounds of mutually independent copies, long and
+// overlapping ones as one cooperative copy each.  Everything else -- long literal runs, very long matches, bad offsets,
+// the ends of the block -- is left to the exact sequential step of
 // wave_decode_block, which also owns liblz4's accept/reject rules.  Returns the number of sequences decoded.
 // Caller guarantees ip0 + 160 <= iend and op0 + 1088 <= oend (the reference is in its fast loop there).
 DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int* ipp, int64_t* opp,
@@ -972,7 +973,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
     const int ip0 = *ipp; const int64_t op0 = *opp;
     // every lane holds the 16 input bytes from its window position on; normally requested by the previous batch
     if (*winIp != ip0) { LANES({ win[I_] = *(const v16u_t*)(src + ip0 + LANE); }) }
-    LV(uint32_t, b0); LV(int, ll); LV(int, ml); LV(int, off); LV(int, nxt); LV(int, outLen); LV(int, plain);
+    LV(uint32_t, b0); LV(int, ll); LV(int, ml); LV(int, off); LV(int, nxt); LV(int, outLen); LV(int, plain); LV(int, coop);
     LANES({
         const uint64_t w0 = (uint64_t)win[I_].w[0] | ((uint64_t)win[I_].w[1] << 32);
         const uint64_t w1 = (uint64_t)win[I_].w[2] | ((uint64_t)win[I_].w[3] << 32);
@@ -983,9 +984,17 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         const uint64_t sel = (l <= 5) ? w0 : (l <= 9 ? ((w0 >> 32) | (w1 << 32)) : w1);
         const int      sft = 8 * (1 + l - (l <= 5 ? 0 : (l <= 9 ? 4 : 8)));
         const uint32_t o16 = (uint32_t)((sel >> sft) & 0xFFFF);
-        b0[I_] = t; ll[I_] = l; ml[I_] = mn + kMinMatch; off[I_] = (int)o16;
-        nxt[I_] = offAt + 2; outLen[I_] = l + mn + kMinMatch;
-        plain[I_] = (l < 14) && (mn < 15) && (offAt <= 64) && (o16 >= (uint32_t)(mn + kMinMatch));
+        // a long match (nibble 15) with a single extension byte, byte 3+l of the 16 (l <= 12)
+        const bool     lng = (mn == 15);
+        const int      ek  = 3 + l;
+        const uint32_t e   = (uint32_t)(((ek < 8) ? (w0 >> (8 * ek)) : (w1 >> (8 * (ek & 7)))) & 0xFF);
+        const int      mlen = lng ? 19 + (int)e : mn + kMinMatch;
+        const bool parse = (l < 14) && (offAt <= 64) && (!lng || (l <= 12 && e < 255));
+        const bool simple = parse && !lng && o16 >= (uint32_t)mlen;     // per-lane copy of <= 18 bytes, no overlap
+        b0[I_] = t; ll[I_] = l; ml[I_] = mlen; off[I_] = (int)o16;
+        nxt[I_] = offAt + 2 + (lng ? 1 : 0); outLen[I_] = l + mlen;
+        coop[I_]  = parse && !simple && o16 >= 1;                       // long or overlapping: one cooperative copy
+        plain[I_] = simple || coop[I_];
     })
     const uint64_t plainMask = BALLOT(plain[I_]);
     uint64_t members = 0;
@@ -1002,9 +1011,10 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
             outStart[I_] = (int)op0 + acc[I_] - (((mL >> LANE) & 1) ? outLen[I_] : 0);
             sp[I_]       = outStart[I_] + ll[I_] - off[I_];                     // where the match bytes come from
         })
-        // a source before the start of the output is the sequential step's business (error, or a dictionary)
-        const uint64_t neg = BALLOT(((mL >> LANE) & 1) && sp[I_] < 0);
-        if (neg) members &= (1ull << ctz64(neg)) - 1;
+        // a source before the start of the output is the sequential step's business (error, or a dictionary);
+        // and the batch's output stays inside the room the caller checked
+        const uint64_t stop = BALLOT(((mL >> LANE) & 1) && (sp[I_] < 0 || acc[I_] > 1024));
+        if (stop) members &= (1ull << ctz64(stop)) - 1;
     }
     if (!members) return 0;
     const uint64_t mL = members;
@@ -1015,7 +1025,8 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
     *winIp = ipn;
     // Match bytes, 4..18 per member lane.  "Far" sources end before this batch's output: all of them are copied at once.
     // A "near" source may contain bytes this batch produces; those go in dependency order below.
-    const uint64_t far = mL & BALLOT((int64_t)sp[I_] + ml[I_] <= op0);
+    const uint64_t coopM = mL & BALLOT(coop[I_]);
+    const uint64_t far = mL & ~coopM & BALLOT((int64_t)sp[I_] + ml[I_] <= op0);
     auto copy_matches = [&](const uint64_t who) {
         LANES({
             if ((who >> LANE) & 1) {
@@ -1042,15 +1053,21 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         const int os = SHFL(outStart, m), lm = SHFL(ll, m);
         if (upto && LANE > m && LANE <= m + lm) dst[os + (LANE - m - 1)] = (uint8_t)b0[I_];
     })
-    // near matches: each round takes every pending one whose source ends before the first pending match's output
-    // (the first one always qualifies: offset >= length), so nothing it reads is still to be written
+    // the rest in dependency order.  Near matches: a round takes every pending one whose source ends before the first
+    // pending match's output (the first one always qualifies: offset >= length), so nothing it reads is still to be
+    // written.  Long or overlapping matches: one cooperative copy each, when they come first.
     for (uint64_t pend = mL & ~far; pend; ) {
         const int f  = ctz64(pend);
         const int lo = RL(outStart, f) + RL(ll, f);
-        const uint64_t go = pend & BALLOT(sp[I_] + ml[I_] <= lo);
         WAVE_FENCE();
-        copy_matches(go);
-        pend &= ~go;
+        if ((coopM >> f) & 1) {
+            wave_copy_match(dst, lo, RL(off, f), RL(ml, f));
+            pend &= pend - 1;
+        } else {
+            const uint64_t go = pend & ~coopM & BALLOT(sp[I_] + ml[I_] <= lo);
+            copy_matches(go);
+            pend &= ~go;
+        }
     }
     *ipp = ipn;
     *opp = (int64_t)RL(outStart, last) + RL(outLen, last);
