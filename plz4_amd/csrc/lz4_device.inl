@@ -189,26 +189,29 @@ DEV int emit_len_ext(uint8_t* dst, int op, int rest)
 }
 
 // ---- grid mode helpers -----------------------------------------------------------------------------------
-// 24 bytes around a position x: [x-4, x+20).  back = the 4 bytes before x (as a little-endian u32, byte 3 is
-// x-1), seq = [x, x+8), f1 = [x+8, x+16), f2 = [x+16, x+20).
-struct Win24 { uint32_t back; uint64_t seq; uint64_t f1; uint32_t f2; };
+// 24 bytes around a position x: [x-4, x+20), as the six dwords the two loads deliver (dwordx4 + dwordx2).  They are kept
+// exactly as loaded -- no repacking into wider fields -- so that nothing has to touch them (and wait for them) before the
+// point of use: w[0] = the 4 bytes before x (byte 3 is x-1), w[1..2] = [x, x+8), w[3..5] = [x+8, x+20).
+struct Win24 { uint32_t w[6]; };
+struct __attribute__((packed, may_alias)) v8u_t { uint32_t w[2]; };
+DEV uint64_t win_seq(const Win24& p) { return (uint64_t)p.w[1] | ((uint64_t)p.w[2] << 32); }
 
 template <bool kMayBeLow>
 DEV Win24 load_win24(const uint8_t* src, int x)
 {
     Win24 w;
     if (!kMayBeLow || x >= 4) {
-        const v16u_t a = *(const v16u_t*)(src + x - 4);           // [x-4, x+12)
-        const uint64_t b = ld64u(src + x + 12);                     // [x+12, x+20)
-        w.back = a.w[0];
-        w.seq  = (uint64_t)a.w[1] | ((uint64_t)a.w[2] << 32);
-        w.f1   = (uint64_t)a.w[3] | (b << 32);
-        w.f2   = (uint32_t)(b >> 32);
+        // three loads whose register tuples are the tuples the users want ([x, x+8) and [x+8, x+16) as 64-bit pairs): a
+        // different split makes the compiler re-pack right behind the loads, i.e. wait for them on the spot
+        const v8u_t  a = *(const v8u_t*)(src + x);                // [x, x+8)
+        const v16u_t b = *(const v16u_t*)(src + x + 8);           // [x+8, x+24): 4 bytes more than needed, still inside the block
+        w.w[0] = ld32u(src + x - 4);
+        w.w[1] = a.w[0]; w.w[2] = a.w[1]; w.w[3] = b.w[0]; w.w[4] = b.w[1]; w.w[5] = b.w[2];
     } else {                                                        // candidates in the first 4 bytes of the block
         uint32_t bk = 0;
         for (int i = 0; i < x; ++i) bk |= (uint32_t)src[x - 1 - i] << (8 * (3 - i));
-        w.back = bk;
-        w.seq = ld64u(src + x); w.f1 = ld64u(src + x + 8); w.f2 = ld32u(src + x + 16);
+        w.w[0] = bk;
+        for (int k = 0; k < 5; ++k) w.w[1 + k] = ld32u(src + x + 4 * k);
     }
     return w;
 }
@@ -216,18 +219,17 @@ DEV Win24 load_win24(const uint8_t* src, int x)
 // equal bytes of [x+4, x+20) in two windows: 0..16
 DEV int win_fwd(const Win24& p, const Win24& c)
 {
-    const uint32_t x0 = (uint32_t)(p.seq >> 32) ^ (uint32_t)(c.seq >> 32);
-    if (x0) return __builtin_ctz(x0) >> 3;
-    const uint64_t x1 = p.f1 ^ c.f1;
-    if (x1) return 4 + (ctz64(x1) >> 3);
-    const uint32_t x2 = p.f2 ^ c.f2;
-    if (x2) return 12 + (__builtin_ctz(x2) >> 3);
-    return 16;
+    const uint32_t x2 = p.w[2] ^ c.w[2], x3 = p.w[3] ^ c.w[3], x4 = p.w[4] ^ c.w[4], x5 = p.w[5] ^ c.w[5];
+    int n = x5 ? 12 + (__builtin_ctz(x5) >> 3) : 16;
+    n = x4 ? 8 + (__builtin_ctz(x4) >> 3) : n;
+    n = x3 ? 4 + (__builtin_ctz(x3) >> 3) : n;
+    n = x2 ? (__builtin_ctz(x2) >> 3) : n;
+    return n;
 }
 // equal bytes going backwards from x-1: 0..4
 DEV int win_bck(const Win24& p, const Win24& c)
 {
-    const uint32_t y = p.back ^ c.back;
+    const uint32_t y = p.w[0] ^ c.w[0];
     return y ? (__builtin_clz(y) >> 3) : 4;
 }
 
@@ -297,7 +299,86 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
         int  width   = 16;                         // generic batches: 16 lanes first, 64 when a search drags on
         LV(Win24, Pn); int prefBase = -1;          // next window's bytes, requested one batch ahead
         LV(Win24, Pc);                             // this window's bytes (kept: a wrong twin is repaired from them)
-        LANES({ Pn[I_].back = 0; Pn[I_].seq = 0; Pn[I_].f1 = 0; Pn[I_].f2 = 0; Pc[I_] = Pn[I_]; })
+        LANES({ for (int k = 0; k < 6; ++k) Pn[I_].w[k] = 0; Pc[I_] = Pn[I_]; })
+
+        // A grid batch does not write its sequences right away: they are kept here and written while the NEXT batch's
+        // candidate bytes are on their way from memory (or before anything else touches the output).
+        uint64_t pMm = 0; int pBase = 0, pAnchor0 = 0, pCur0 = 0; bool pRe0 = false;
+        LV(int, pFwd); LV(int, pBck); LV(uint32_t, pR); LV(uint32_t, pLit8); LV(int, pStA); LV(int, pHasPm);
+        LANES({ pFwd[I_] = 0; pBck[I_] = 0; pR[I_] = 0; pLit8[I_] = 0; pStA[I_] = 0; pHasPm[I_] = 0; })
+        // ---- 4. emit every recorded sequence of the pending batch at once.  False: liblz4 would return 0 (limitedOutput).
+        auto flush_emit = [&]() -> bool {
+            if (!pMm) return true;
+            const uint64_t mm = pMm; const int base = pBase; const int anchor0 = pAnchor0; const int cur0 = pCur0; const bool re0 = pRe0;
+            pMm = 0;
+            LV(int, anc); LV(int, lit); LV(int, mcT); LV(int, extL); LV(int, extM); LV(int, size); LV(int, tok);
+            LV(int, pS); LV(int, litDst);
+            LANES({ anc[I_] = pHasPm[I_] ? base + pStA[I_] : anchor0; })
+            {   // catch-up that may go past the 4 speculative bytes (rare): finish it now that the anchors are final
+                const uint64_t mmB = mm;
+                uint64_t deep = BALLOT(((mmB >> LANE) & 1) && pBck[I_] == 4 && min_(base + LANE - anc[I_], (int)pR[I_]) > 4);
+                for (; deep; deep &= deep - 1) {
+                    const int w = ctz64(deep);
+                    const int p0 = base + w, c0 = (int)RL(pR, w);
+                    const int maxBack = min_(p0 - RL(anc, w), c0);
+                    STAT(S_LONGBACK, 1);
+                    WL(pBck, w, 4 + wave_common_back(src, p0 - 4, c0 - 4, maxBack - 4));
+                }
+            }
+            LANES({
+                const int q = base + LANE;
+                const int bk = min_(pBck[I_], min_(q - anc[I_], (int)pR[I_]));     // lz4.c:1105-1109 (0 for a re-test)
+                pS[I_]   = q - bk;
+                lit[I_]  = q - bk - anc[I_];
+                mcT[I_]  = pFwd[I_] + bk;
+                extL[I_] = lit[I_] >= 15 ? (lit[I_] - 15) / 255 + 1 : 0;
+                extM[I_] = mcT[I_] >= 15 ? (mcT[I_] - 15) / 255 + 1 : 0;
+                size[I_] = 1 + extL[I_] + lit[I_] + 2 + extM[I_];
+                tok[I_]  = 0;
+            })
+            for (uint64_t m = mm; m; m &= m - 1) {            // output cursor per sequence, in order
+                const int w = ctz64(m);
+                WL(tok, w, op);
+                op += RL(size, w);
+            }
+            const uint64_t mmL = mm;
+            // lz4.c:1114-1117 and :1187-1210, per sequence.  Every left-hand side is <= (end of this batch's output) + 7,
+            // so the exact per-sequence test is only needed near the end of the capacity.
+            if (limited && (int64_t)op + 8 > cap) {
+                const uint64_t over = BALLOT(((mmL >> LANE) & 1) &&
+                    ((!(pHasPm[I_] ? (LANE == pStA[I_]) : (re0 && LANE == cur0)) &&
+                      (int64_t)tok[I_] + 1 + lit[I_] + (2 + 1 + kLastLiterals) + lit[I_] / 255 > cap) ||
+                     ((int64_t)tok[I_] + 1 + extL[I_] + lit[I_] + 2 + (1 + kLastLiterals) + (mcT[I_] + 240) / 255 > cap)));
+                if (over) return false;
+            }
+            LANES({
+                litDst[I_] = tok[I_] + 1 + extL[I_];
+                if ((mmL >> LANE) & 1) {
+                    const int t = tok[I_];
+                    dst[t] = (uint8_t)((min_(lit[I_], 15) << 4) | min_(mcT[I_], 15));
+                    int o = t + 1;
+                    if (extL[I_]) { int rest = lit[I_] - 15; for (; rest >= 255; rest -= 255) dst[o++] = 255; dst[o++] = (uint8_t)rest; }
+                    o += lit[I_];
+                    st16u(dst + o, (uint16_t)((uint32_t)(base + LANE) - pR[I_]));
+                    o += 2;
+                    if (extM[I_]) { int rest = mcT[I_] - 15; for (; rest >= 255; rest -= 255) dst[o++] = 255; dst[o++] = (uint8_t)rest; }
+                }
+            })
+            // literals: every lane looks up the next recorded match at or after it
+            LANES({
+                const uint64_t ahead = mmL >> LANE;
+                const int m = ahead ? LANE + ctz64(ahead) : LANE;   // all lanes take part in the exchange
+                const int a = SHFL(anc, m), pe = SHFL(pS, m), ld = SHFL(litDst, m);
+                const int q = base + LANE;
+                if (ahead && q >= a && q < pe) dst[ld + (q - a)] = (uint8_t)pLit8[I_];
+            })
+            {   // the part of the first run that lies before this window comes from memory
+                const int w0 = ctz64(mm);
+                const int a0 = RL(anc, w0);
+                if (a0 < base) { STAT(S_MEMLIT, 1); wave_copy(dst + RL(litDst, w0), src + a0, min_(RL(lit, w0), base - a0)); }
+            }
+            return true;
+        };
 
         for (;;) {
             // ================================================================ GRID batch
@@ -311,39 +392,43 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                     const unsigned long long tg0 = STAT_NOW(); (void)tg0;
                     LV(int, act); LV(uint32_t, h); LV(uint32_t, r); LV(uint32_t, lit8);
                     LV(uint32_t, ent); LV(uint32_t, rent);           // my table entry / the entry I displaced
-                    LV(int, hit); LV(int, fwd); LV(int, bck); LV(int, eLane);
-                    // ---- 1. every lane: its window, the table exchange, its candidate's window
+                    LV(int, hit); LV(int, fwd); LV(int, bck); LV(int, eLane); LV(int, cand); LV(Win24, Cw);
+                    // ---- 1. every lane: its window, the table exchange, the request for its candidate's window
                     LANES({
                         const int q = base + LANE;
                         const int isIns = hasIns && q == insPos;
                         act[I_] = isIns || q >= probeStart;
-                        hit[I_] = 0; fwd[I_] = 0; bck[I_] = 0; r[I_] = 0; h[I_] = 0; ent[I_] = 0; rent[I_] = 0;
+                        hit[I_] = 0; fwd[I_] = 0; bck[I_] = 0; r[I_] = 0; h[I_] = 0; ent[I_] = 0; rent[I_] = 0; cand[I_] = 0;
                         const Win24 P = (base == prefBase) ? Pn[I_] : load_win24<false>(src, q);   // every lane: its byte may be a pending literal
                         Pc[I_] = P;
-                        lit8[I_] = (uint32_t)(P.seq & 0xFF);
+                        lit8[I_] = P.w[1] & 0xFF;
                         if (act[I_]) {
-                            h[I_] = seq_hash<false>(P.seq);
-                            const uint32_t tg = seq_tag((uint32_t)P.seq) & tagMask;
+                            h[I_] = seq_hash<false>(win_seq(P));
+                            const uint32_t tg = seq_tag(P.w[1]) & tagMask;
                             ent[I_]  = ((uint32_t)q << sh) | tg;
                             rent[I_] = lds_max_rtn(&T[h[I_]], ent[I_]);
                             r[I_]    = rent[I_] >> sh;
-                            if (!isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q && (rent[I_] & tagMask) == tg) {
-                                const Win24 Cw = load_win24<true>(src, (int)r[I_]);
-                                if ((uint32_t)Cw.seq == (uint32_t)P.seq) {
-                                    hit[I_] = 1;
-                                    fwd[I_] = win_fwd(P, Cw);
-                                    bck[I_] = min_(win_bck(P, Cw), (int)r[I_]);
-                                }
-                            }
+                            cand[I_] = !isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q && (rent[I_] & tagMask) == tg;
+                            if (cand[I_] && r[I_] >= 4) Cw[I_] = load_win24<false>(src, (int)r[I_]);
                         }
-                        eLane[I_] = LANE + kMinMatch + fwd[I_];     // lane index just past a match that starts here
                         if (base + 160 <= n) Pn[I_] = load_win24<false>(src, q + 64);   // request the next window now, use it next batch
                     })
                     prefBase = (base + 160 <= n) ? base + 64 : -1;
+                    // the previous batch's sequences are written while those bytes travel
+                    if (!flush_emit()) return 0;
+                    LANES({
+                        if (act[I_] && cand[I_] && Cw[I_].w[1] == Pc[I_].w[1]) {
+                            hit[I_] = 1;
+                            fwd[I_] = win_fwd(Pc[I_], Cw[I_]);
+                            bck[I_] = min_(win_bck(Pc[I_], Cw[I_]), (int)r[I_]);
+                        }
+                        eLane[I_] = LANE + kMinMatch + fwd[I_];     // lane index just past a match that starts here
+                    })
                     LDS_FENCE();
                     // LDS atomics on one slot are expected to resolve in ascending lane order (then r is the
                     // nearest earlier twin or the pre-batch value).  Any other order shows up as r >= q somewhere.
-                    const uint64_t misorder = BALLOT(act[I_] && r[I_] >= (uint32_t)(base + LANE));
+                    // (A candidate in the first 4 bytes of the block has no 4 bytes before it to load: equally rare, same way out.)
+                    const uint64_t misorder = BALLOT(act[I_] && (r[I_] >= (uint32_t)(base + LANE) || (cand[I_] && r[I_] < 4)));
                     if (misorder) {
                         STAT(S_MISORDER, 1);
                         LANES({ if (act[I_]) lds_min(&T[h[I_]], rent[I_]); })  // min over a slot's group == its pre-batch value
@@ -440,11 +525,11 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                     const uint32_t cp = ce >> sh, qb = (uint32_t)(base + b);
                                     int nhit = 0, nfwd = 0, nbck = 0;
                                     if (cp + kMaxDist >= qb && (ce & tagMask) == (RL(ent, b) & tagMask)) {
-                                        Win24 Pb; Pb.back = RLF(Pc, back, b); Pb.seq = RLF(Pc, seq, b); Pb.f1 = RLF(Pc, f1, b); Pb.f2 = RLF(Pc, f2, b);
+                                        Win24 Pb; for (int k = 0; k < 6; ++k) Pb.w[k] = RLF(Pc, w[k], b);
                                         Win24 Cw;
-                                        if (cp >= (uint32_t)base) { const int t = (int)cp - base; Cw.back = RLF(Pc, back, t); Cw.seq = RLF(Pc, seq, t); Cw.f1 = RLF(Pc, f1, t); Cw.f2 = RLF(Pc, f2, t); }
-                                        else { Cw = load_win24<true>(src, (int)cp); Cw.back = UNI(Cw.back); Cw.seq = UNI(Cw.seq); Cw.f1 = UNI(Cw.f1); Cw.f2 = UNI(Cw.f2); }
-                                        if ((uint32_t)Cw.seq == (uint32_t)Pb.seq) { nhit = 1; nfwd = win_fwd(Pb, Cw); nbck = min_(win_bck(Pb, Cw), (int)cp); }
+                                        if (cp >= (uint32_t)base) { const int t = (int)cp - base; for (int k = 0; k < 6; ++k) Cw.w[k] = RLF(Pc, w[k], t); }
+                                        else { Cw = load_win24<true>(src, (int)cp); for (int k = 0; k < 6; ++k) Cw.w[k] = UNI(Cw.w[k]); }
+                                        if (Cw.w[1] == Pb.w[1]) { nhit = 1; nfwd = win_fwd(Pb, Cw); nbck = min_(win_bck(Pb, Cw), (int)cp); }
                                     }
                                     WL(rent, b, ce); WL(r, b, cp); WL(hit, b, nhit); WL(fwd, b, nfwd); WL(bck, b, nbck);
                                     WL(eLane, b, b + kMinMatch + nfwd);
@@ -462,75 +547,11 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         STAT(S_SEQ_GRID, __builtin_popcountll(mm));
                         STAT(S_LANES_EXEC, __builtin_popcountll(E));
 
-                        // ---- 4. emit every recorded sequence at once
+                        // ---- 4. hand the recorded sequences to the deferred writer (flush_emit)
                         if (mm) {
-                            LV(int, anc); LV(int, lit); LV(int, mcT); LV(int, extL); LV(int, extM); LV(int, size); LV(int, tok);
-                            LV(int, pS); LV(int, litDst);
-                            const int anchor0 = anchor;
-                            LANES({ anc[I_] = hasPm[I_] ? base + stA[I_] : anchor0; })
-                            {   // catch-up that may go past the 4 speculative bytes (rare): finish it now that the anchors are final
-                                const uint64_t mmB = mm;
-                                uint64_t deep = BALLOT(((mmB >> LANE) & 1) && bck[I_] == 4 && min_(base + LANE - anc[I_], (int)r[I_]) > 4);
-                                for (; deep; deep &= deep - 1) {
-                                    const int w = ctz64(deep);
-                                    const int p0 = base + w, c0 = (int)RL(r, w);
-                                    const int maxBack = min_(p0 - RL(anc, w), c0);
-                                    STAT(S_LONGBACK, 1);
-                                    WL(bck, w, 4 + wave_common_back(src, p0 - 4, c0 - 4, maxBack - 4));
-                                }
-                            }
-                            LANES({
-                                const int q = base + LANE;
-                                const int bk = min_(bck[I_], min_(q - anc[I_], (int)r[I_]));     // lz4.c:1105-1109 (0 for a re-test)
-                                pS[I_]   = q - bk;
-                                lit[I_]  = q - bk - anc[I_];
-                                mcT[I_]  = fwd[I_] + bk;
-                                extL[I_] = lit[I_] >= 15 ? (lit[I_] - 15) / 255 + 1 : 0;
-                                extM[I_] = mcT[I_] >= 15 ? (mcT[I_] - 15) / 255 + 1 : 0;
-                                size[I_] = 1 + extL[I_] + lit[I_] + 2 + extM[I_];
-                                tok[I_]  = 0;
-                            })
-                            for (uint64_t m = mm; m; m &= m - 1) {            // output cursor per sequence, in order
-                                const int w = ctz64(m);
-                                WL(tok, w, op);
-                                op += RL(size, w);
-                            }
-                            const uint64_t mmL = mm;
-                            // lz4.c:1114-1117 and :1187-1210, per sequence.  Every left-hand side is <= (end of this batch's output) + 7,
-                            // so the exact per-sequence test is only needed near the end of the capacity.
-                            if (limited && (int64_t)op + 8 > cap) {
-                                const uint64_t over = BALLOT(((mmL >> LANE) & 1) &&
-                                    ((!(hasPm[I_] ? (LANE == stA[I_]) : (re0 && LANE == cur0)) &&
-                                      (int64_t)tok[I_] + 1 + lit[I_] + (2 + 1 + kLastLiterals) + lit[I_] / 255 > cap) ||
-                                     ((int64_t)tok[I_] + 1 + extL[I_] + lit[I_] + 2 + (1 + kLastLiterals) + (mcT[I_] + 240) / 255 > cap)));
-                                if (over) return 0;
-                            }
-                            LANES({
-                                litDst[I_] = tok[I_] + 1 + extL[I_];
-                                if ((mmL >> LANE) & 1) {
-                                    const int t = tok[I_];
-                                    dst[t] = (uint8_t)((min_(lit[I_], 15) << 4) | min_(mcT[I_], 15));
-                                    int o = t + 1;
-                                    if (extL[I_]) { int rest = lit[I_] - 15; for (; rest >= 255; rest -= 255) dst[o++] = 255; dst[o++] = (uint8_t)rest; }
-                                    o += lit[I_];
-                                    st16u(dst + o, (uint16_t)((uint32_t)(base + LANE) - r[I_]));
-                                    o += 2;
-                                    if (extM[I_]) { int rest = mcT[I_] - 15; for (; rest >= 255; rest -= 255) dst[o++] = 255; dst[o++] = (uint8_t)rest; }
-                                }
-                            })
-                            // literals: every lane looks up the next recorded match at or after it
-                            LANES({
-                                const uint64_t ahead = mmL >> LANE;
-                                const int m = ahead ? LANE + ctz64(ahead) : LANE;   // all lanes take part in the exchange
-                                const int a = SHFL(anc, m), pe = SHFL(pS, m), ld = SHFL(litDst, m);
-                                const int q = base + LANE;
-                                if (ahead && q >= a && q < pe) dst[ld + (q - a)] = (uint8_t)lit8[I_];
-                            })
-                            {   // the part of the first run that lies before this window comes from memory
-                                const int w0 = ctz64(mm);
-                                const int a0 = RL(anc, w0);
-                                if (a0 < base) { STAT(S_MEMLIT, 1); wave_copy(dst + RL(litDst, w0), src + a0, min_(RL(lit, w0), base - a0)); }
-                            }
+                            pMm = mm; pBase = base; pAnchor0 = anchor; pCur0 = cur0; pRe0 = re0;
+                            LANES({ pFwd[I_] = fwd[I_]; pBck[I_] = bck[I_]; pR[I_] = r[I_]; pLit8[I_] = lit8[I_];
+                                    pStA[I_] = stA[I_]; pHasPm[I_] = hasPm[I_]; })
                             anchor = base + eL;
                         }
                         const unsigned long long tg3 = STAT_NOW(); (void)tg3;
@@ -564,6 +585,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
 generic_batch:
             // ================================================================ GENERIC batch
             {
+            if (!flush_emit()) return 0;
             STAT(S_GENERIC, 1);
             const unsigned long long tq0 = STAT_NOW(); (void)tq0;
             const int pre = (hasIns ? 1 : 0) + (hasRe ? 1 : 0);
@@ -675,6 +697,7 @@ generic_batch:
             STAT(S_CYC_GEN, STAT_NOW() - tq0);
             }
         }
+        if (!flush_emit()) return 0;          // a grid batch may have been the last one
     }
 
     // last literals (lz4.c:1302-1329)

@@ -509,6 +509,9 @@ int plz4hip_ctx_create(int device, plz4hip_ctx** out)
     }
     if (encPer < 1) encPer = 1;
     if (decPer < 1) decPer = 1;
+    // The occupancy query counts ten 16 KiB tables per CU; nine workgroups are what a CU really holds
+    // (scripts/micro/residency.hip), and a tenth would only queue behind them.
+    if (encPer > 9) encPer = 9;
     c->encWaves = c->cus * encPer;
     c->decWaves = c->cus * decPer;
     *out = c;

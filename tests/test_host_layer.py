@@ -174,9 +174,9 @@ def test_write_after_close(eng):
 
 
 def test_unsupported_modes_fail_loudly(eng):
-    """HC levels with linked blocks or a dictionary are not built yet (and the oracle-backed test engine has no HC at
-    all): the writer reports ErrUnsupported, it never falls back to other bytes."""
-    for kw in (dict(level=9), dict(level=9, block_linked=True), dict(level=12, block_linked=True), dict(level=2, dictionary=b"abcd" * 64)):
+    """HC levels with linked blocks or a dictionary are not built yet: the writer reports ErrUnsupported, it never falls
+    back to other bytes."""
+    for kw in (dict(level=9, block_linked=True), dict(level=12, block_linked=True), dict(level=2, dictionary=b"abcd" * 64)):
         w = host.Writer(eng, parallel=1, **kw)
         w.write(b"some payload that needs compressing")
         assert int(w.close()) == host.ErrUnsupported
