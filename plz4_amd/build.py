@@ -38,7 +38,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -fno-slp-vectorize: the SLP pass pairs up the dwords of freshly loaded windows into 64-bit values, which puts register
+    # copies (and therefore a wait for the load) directly behind loads whose latency the kernels mean to overlap
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared",
            "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-o", LIB] + sources()
     if verbose:
         print(" ".join(cmd))

@@ -10,7 +10,7 @@ from plz4_amd import synth, _native
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 so = os.path.join(ROOT, "scripts", "_build", "libplz4hip_stats.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DPLZ4_STATS",
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-fPIC", "-shared", "-DPLZ4_STATS",
                        "-Wno-unused-value", "-I", os.path.join(ROOT, "include"), "-o", so,
                        os.path.join(ROOT, "plz4_amd", "csrc", "plz4hip.hip")])
 _native.LIB_PATH = so
