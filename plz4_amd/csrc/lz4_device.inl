@@ -336,12 +336,15 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                 size[I_] = 1 + extL[I_] + lit[I_] + 2 + extM[I_];
                 tok[I_]  = 0;
             })
-            for (uint64_t m = mm; m; m &= m - 1) {            // output cursor per sequence, in order
-                const int w = ctz64(m);
-                WL(tok, w, op);
-                op += RL(size, w);
-            }
             const uint64_t mmL = mm;
+            {   // output cursor per sequence, in order: a prefix sum over the match lanes
+                LV(int, acc);
+                LANES({ acc[I_] = ((mmL >> LANE) & 1) ? size[I_] : 0; })
+                SCAN_INCL(acc);
+                const int op0 = op;
+                LANES({ tok[I_] = op0 + acc[I_] - size[I_]; })
+                op = op0 + RL(acc, 63);
+            }
             // lz4.c:1114-1117 and :1187-1210, per sequence.  Every left-hand side is <= (end of this batch's output) + 7,
             // so the exact per-sequence test is only needed near the end of the capacity.
             if (limited && (int64_t)op + 8 > cap) {
@@ -456,6 +459,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         bool     finished = false;
                         LV(int, stA); LV(int, hasPm);
                         for (;;) {
+                            const unsigned long long th0 = STAT_NOW(); (void)th0;
                             const uint64_t hitsS = (S >= 64) ? hits : (hits & ((1ull << S) - 1));
                             LV(int, nextHit);
                             LANES({
@@ -463,37 +467,37 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                 nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
                             })
                             mm = 0; eL = 0; finished = false;
+                            const unsigned long long th1 = STAT_NOW(); (void)th1;
+                            STAT(S_DBATCH, th1 - th0);
                             int w = 64;
                             if (cur0 < S) { const uint64_t hm = hitsS & (~0ull << cur0); if (hm) w = ctz64(hm); }
                             if (w < S && w <= lim0) {
-                                int aCur = anchor;
-                                for (;;) {
+                                // one exit test per hop: nextHit[w] >= eLane[w], so running past S ends the walk by itself
+                                do {
                                     STAT(S_WALKITER, 1);
+                                    int nw;
                                     if ((specialLeft >> w) & 1) {
-                                        // longer than the speculative window (forwards and/or backwards): finish it now
+                                        // longer than the speculative window: finish it now
                                         const int p0 = base + w, c0 = (int)RL(r, w);
                                         int mc0 = (int)RL(fwd, w);
                                         if (mc0 == 16) { STAT(S_SAT, 1); mc0 += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); WL(fwd, w, mc0); }
                                         specialLeft &= ~(1ull << w);
                                         eL = w + kMinMatch + mc0;
                                         WL(eLane, w, eL);
-                                        mm |= 1ull << w;
-                                        aCur = base + eL;
-                                        if (aCur >= lastProbe) { finished = true; break; }        // lz4.c:1233
-                                        if (eL >= S) break;
-                                        const uint64_t hm = hitsS & (~0ull << eL);
-                                        w = hm ? ctz64(hm) : 64;
+                                        const uint64_t hm = (eL < 64) ? (hitsS & (~0ull << eL)) : 0;
+                                        nw = hm ? ctz64(hm) : 64;
+                                        if (base + eL >= lastProbe) { finished = true; nw = 64; }   // lz4.c:1233 (only a long match gets there)
                                     } else {
-                                        mm |= 1ull << w;
                                         eL = RL(eLane, w);
-                                        aCur = base + eL;
-                                        if (eL >= S) break;
-                                        w = RL(nextHit, w);
+                                        nw = RL(nextHit, w);
                                     }
-                                    if (w >= S) break;
-                                }
+                                    mm |= 1ull << w;
+                                    w = nw;
+                                } while (w < S);
                             }
                             // ---- 3. which lanes did the sequential parser execute
+                            const unsigned long long th2 = STAT_NOW(); (void)th2;
+                            STAT(S_DMEMB, th2 - th1);
                             Send = mm ? S : min_(S, lim0 + 1);
                             const uint64_t mmL = mm; const int SendL = Send;
                             LANES({
@@ -505,6 +509,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             })
                             const uint64_t probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
                             E = probes | insBit0 | BALLOT(hasPm[I_] && stA[I_] == LANE + 2);   // + the ip-2 inserts (lz4.c:1236-1242)
+                            const unsigned long long th3 = STAT_NOW(); (void)th3;
+                            STAT(S_DSEQ, th3 - th2);
                             if (twins & probes) {
                                 // A probe whose candidate is an earlier lane of this batch is only right if that lane was executed.
                                 // Otherwise the sequential parser saw what that lane displaced (or what *it* displaced, ...):
@@ -537,6 +543,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                     hits = nhit ? (hits | bit) : (hits & ~bit);
                                     specialLeft = (nhit && nfwd == 16) ? (specialLeft | bit) : (specialLeft & ~bit);
                                     twins &= ~bit;
+                                    STAT(S_DSEQ_ML15, STAT_NOW() - th3);
                                     continue;
                                 }
                             }

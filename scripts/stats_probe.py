@@ -42,6 +42,8 @@ for chk in (True, False):
     g = max(v["grid"], 1)
     print("   per grid batch: phase1 %.0f cyc, hop %.0f cyc, emit %.0f cyc, fix %.0f cyc, seqs %.2f, lanes exec %.1f, walk iters %.2f"
           % (v["cyc_load"] / g, v["cyc_walk"] / g, v["cyc_sat"] / g, v["cyc_fix"] / g, v["seq_grid"] / g, v["lanes_exec"] / g, v["walkiter"] / g))
+    print("   hop split per grid batch: nextHit %.0f, walk %.0f, derive %.0f, repair %.0f cyc"
+          % (v["dbatch"] / g, v["dmemb"] / g, v["dseq"] / g, v["dseq_ml15"] / g))
     print("   per generic batch: %.0f cyc;  total cyc/block %.3e" % (v["cyc_gen"] / max(v["generic"], 1), v["cyc_total"] / nb))
 
 # decode stats
