@@ -472,28 +472,37 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             int w = 64;
                             if (cur0 < S) { const uint64_t hm = hitsS & (~0ull << cur0); if (hm) w = ctz64(hm); }
                             if (w < S && w <= lim0) {
-                                // one exit test per hop: nextHit[w] >= eLane[w], so running past S ends the walk by itself
-                                do {
-                                    STAT(S_WALKITER, 1);
-                                    int nw;
-                                    if ((specialLeft >> w) & 1) {
-                                        // longer than the speculative window: finish it now
-                                        const int p0 = base + w, c0 = (int)RL(r, w);
-                                        int mc0 = (int)RL(fwd, w);
-                                        if (mc0 == 16) { STAT(S_SAT, 1); mc0 += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); WL(fwd, w, mc0); }
-                                        specialLeft &= ~(1ull << w);
-                                        eL = w + kMinMatch + mc0;
-                                        WL(eLane, w, eL);
-                                        const uint64_t hm = (eL < 64) ? (hitsS & (~0ull << eL)) : 0;
-                                        nw = hm ? ctz64(hm) : 64;
-                                        if (base + eL >= lastProbe) { finished = true; nw = 64; }   // lz4.c:1233 (only a long match gets there)
-                                    } else {
-                                        eL = RL(eLane, w);
-                                        nw = RL(nextHit, w);
-                                    }
-                                    mm |= 1ull << w;
-                                    w = nw;
-                                } while (w < S);
+                                // Hops come four to a branch (a taken branch costs more than the hop): once the walk has run
+                                // past S the remaining steps of a group change nothing (nextHit[w] >= eLane[w] >= S ends it).
+                                // Matches longer than the speculative window are not known to the hop: it walks through them
+                                // as if they ended there, and the first one it touched is put right afterwards.
+                                for (;;) {
+                                    do {
+                                        STAT(S_WALKITER, 1);
+                                        for (int u = 0; u < 4; ++u) {
+                                            const bool go = w < S;
+                                            const int  wl = w & 63;
+                                            const int  e1 = RL(eLane, wl), n1 = RL(nextHit, wl);
+                                            mm |= go ? (1ull << wl) : 0ull;
+                                            eL = go ? e1 : eL;
+                                            w  = go ? n1 : w;
+                                        }
+                                    } while (w < S);
+                                    const uint64_t sp = mm & specialLeft;
+                                    if (!sp) break;
+                                    const int ws = ctz64(sp);
+                                    mm &= (2ull << ws) - 1;                       // what the walk did after it is void
+                                    const int p0 = base + ws, c0 = (int)RL(r, ws);
+                                    int mc0 = (int)RL(fwd, ws);
+                                    if (mc0 == 16) { STAT(S_SAT, 1); mc0 += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); WL(fwd, ws, mc0); }
+                                    specialLeft &= ~(1ull << ws);
+                                    eL = ws + kMinMatch + mc0;
+                                    WL(eLane, ws, eL);
+                                    if (base + eL >= lastProbe) { finished = true; break; }   // lz4.c:1233 (only a long match gets there)
+                                    const uint64_t hm = (eL < 64) ? (hitsS & (~0ull << eL)) : 0;
+                                    w = hm ? ctz64(hm) : 64;
+                                    if (w >= S) break;
+                                }
                             }
                             // ---- 3. which lanes did the sequential parser execute
                             const unsigned long long th2 = STAT_NOW(); (void)th2;
