@@ -106,15 +106,17 @@ func NewCompressorFactory(level LevelT, independent bool, dict *DictT) Compresso
 }
 
 func (f CompressorFactory) NewCompressor() Compressor {
-	if f.level != 1 || !f.indie || f.dict != nil {
-		panic("plz4_hip: level 1 / independent blocks / no dictionary only in this round; build without the plz4_hip tag for the rest")
+	// Levels 1..12 are served for independent blocks.  The engine also has level-1 dictionaries and linked blocks
+	// (plz4hip_dict_create, plz4hip_encode_records_ex / decode_records_ex); this thin shim does not bind them yet.
+	if f.level < 1 || f.level > 12 || !f.indie || f.dict != nil {
+		panic("plz4_hip: independent blocks without a dictionary only in this shim; build without the plz4_hip tag for the rest")
 	}
 	return hipCompressor{level: f.level}
 }
 
 func NewDecompressor(independent bool, dict *DictT) Decompressor {
 	if !independent || dict != nil {
-		panic("plz4_hip: linked blocks / dictionaries are not built yet")
+		panic("plz4_hip: linked blocks / dictionaries are not bound by this shim yet")
 	}
 	return hipDecompressor{}
 }

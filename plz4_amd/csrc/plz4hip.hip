@@ -39,7 +39,7 @@ struct CodecArgs {
     int             linked;                         // encode: block i>0 is primed with the tail of block i-1
     const uint8_t*  prevTail;   int prevTailLen;    // linked: window of block 0 (-1: block 0 starts a frame)
     uint8_t*        window;     int* windowLen;     // linked decode: the 64 KiB sliding dictionary (2 x 64 KiB ping-pong), in/out
-    // HC levels 10..12
+    // HC levels 2..12
     int             level;
     uint8_t*        hcWork;                         // gridDim.x x kHcWorkBytes
 };
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(64) void k_decode_raw_dict(CodecArgs a)
     }
 }
 
-// HC optimal parser, levels 10..12 (config 4): LZ4_compress_HC per block; mode 0 = raw LZ4 block, 1 = frame record.
+// HC levels 2..12 (config 4 = level 12): LZ4_compress_HC per block; mode 0 = raw LZ4 block, 1 = frame record.
 __device__ __forceinline__ HcWork hc_work_of(const CodecArgs& a)
 {
     uint8_t* ws = a.hcWork + (size_t)blockIdx.x * kHcWorkBytes;
@@ -576,7 +576,7 @@ int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes
                                int blockChecksum, void* stage, int32_t* recLen, void* stream)
 {
     if (!c || srcBytes < 0 || bsz <= 0 || !stage || !recLen) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_encode_records: bad argument");
-    if (level != 1 && !is_hc_level(level)) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1 and 10..12 are built");
+    if (level != 1 && !is_hc_level(level)) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1..12 are built");
     const int64_t nb64 = (srcBytes + bsz - 1) / bsz;
     if (nb64 > 0x7FFFFFFF) return fail(c, PLZ4HIP_E_ARG, "too many blocks");
     const int nBlocks = (int)nb64;
@@ -780,7 +780,7 @@ int plz4hip_compress_batch(plz4hip_ctx* c, int nBlocks, const void* const* src, 
 {
     if (!c || nBlocks < 0 || (nBlocks && (!src || !srcLen || !dst || !dstCap || !result))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_compress_batch: bad argument");
     if (is_hc_level(level)) { DictJob j; j.level = level; return host_codec(c, 0, nBlocks, src, srcLen, dst, dstCap, 0, 0, result, nullptr, &j); }
-    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1 and 10..12 are built");
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1..12 are built");
     return host_codec(c, 0, nBlocks, src, srcLen, dst, dstCap, 0, 0, result, nullptr);
 }
 
@@ -803,7 +803,7 @@ int plz4hip_encode_records(plz4hip_ctx* c, int nBlocks, const void* const* src, 
     if (!c || nBlocks < 0 || bsz <= 0 || (nBlocks && (!src || !srcLen || !rec || !recLen))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_encode_records: bad argument");
     for (int i = 0; i < nBlocks; ++i) if (srcLen[i] > bsz) return fail(c, PLZ4HIP_E_ARG, "source block larger than block size");
     if (is_hc_level(level)) { DictJob j; j.level = level; return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr, &j); }
-    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1 and 10..12 are built");
+    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1..12 are built");
     return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr);
 }
 
