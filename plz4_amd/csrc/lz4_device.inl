@@ -509,12 +509,13 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             STAT(S_DMEMB, th2 - th1);
                             Send = mm ? S : min_(S, lim0 + 1);
                             const uint64_t mmL = mm; const int SendL = Send;
+                            // end of the last executed match below each lane: ends grow along the walk, so an exclusive
+                            // prefix maximum over the match lanes (DPP, no LDS round trip) is that value
+                            LANES({ stA[I_] = ((mmL >> LANE) & 1) ? eLane[I_] : 0; })
+                            SCAN_MAX_EXCL(stA);
                             LANES({
-                                const uint64_t below = mmL & ((1ull << LANE) - 1);        // match lanes strictly below me
-                                const int pm = below ? 63 - __builtin_clzll(below) : -1;
-                                const int ePrev = SHFL(eLane, pm < 0 ? LANE : pm);
-                                hasPm[I_] = pm >= 0;
-                                stA[I_]   = pm >= 0 ? ePrev : cur0;                        // where probing resumed before me
+                                hasPm[I_] = stA[I_] > 0;
+                                stA[I_]   = hasPm[I_] ? stA[I_] : cur0;                    // where probing resumed before me
                             })
                             const uint64_t probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
                             E = probes | insBit0 | BALLOT(hasPm[I_] && stA[I_] == LANE + 2);   // + the ip-2 inserts (lz4.c:1236-1242)

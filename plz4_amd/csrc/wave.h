@@ -34,6 +34,8 @@
 #define UNI(x)         (x)
 #define LVREF(T, x)    T (&x)[64]                       /* a per-lane variable as a function parameter */
 #define SCAN_INCL(x)   do { for (int s_ = 1; s_ < 64; ++s_) (x)[s_] += (x)[s_ - 1]; } while (0)   /* inclusive prefix sum over lanes */
+/* x[l] <- max of x over the lanes strictly below l (0 for lane 0); x >= 0 */
+#define SCAN_MAX_EXCL(x) do { int m_ = 0; for (int s_ = 0; s_ < 64; ++s_) { const int v_ = (x)[s_]; (x)[s_] = m_; if (v_ > m_) m_ = v_; } } while (0)
 #define WAVE_FENCE()   do {} while (0)
 #define LDS_FENCE()    do {} while (0)
 // Same-address LDS store conflicts inside one instruction are resolved in an unspecified lane order on
@@ -59,6 +61,7 @@ static inline int plz4_emu_step()  { return plz4_emu_descending ? -1 : 1; }
 #define UNI(x)         plz4_readfirstlane((x))
 #define LVREF(T, x)    T (&x)[1]
 #define SCAN_INCL(x)   do { (x)[0] = plz4_scan_incl((x)[0]); } while (0)
+#define SCAN_MAX_EXCL(x) do { (x)[0] = plz4_scan_max_excl((x)[0]); } while (0)
 // Same-wave producer/consumer through memory needs no cache action on CDNA (one TCP, in-order VMEM
 // queue); the fence only stops the compiler from reordering the accesses.
 #define WAVE_FENCE()   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
@@ -83,6 +86,18 @@ __device__ __forceinline__ int plz4_scan_incl(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);    // row_bcast15 -> rows 1, 3
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);    // row_bcast31 -> rows 2, 3
     return v;
+}
+// Exclusive prefix maximum of non-negative values, same network; the final step moves everything up one lane (wave_shr:1).
+__device__ __forceinline__ int plz4_scan_max_excl(int v)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false); v = v > t ? v : t;
+    t = __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false); v = v > t ? v : t;
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true);            // wave_shr:1, lane 0 <- 0
 }
 __device__ __forceinline__ int      plz4_bpermute(int v, int l)      { return __builtin_amdgcn_ds_bpermute(l << 2, v); }
 __device__ __forceinline__ uint32_t plz4_bpermute(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_ds_bpermute(l << 2, (int)v); }
