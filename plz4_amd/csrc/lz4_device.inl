@@ -451,7 +451,6 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         int lim0 = sBase + 65 - base; if (lim0 > 63) lim0 = 63;   // probe number <= 65 keeps the stride at 1
 
                         // ---- 2. scalar hop over the recorded matches only; everything else is derived per lane
-                        int      S = 64;           // first lane NOT executed as a probe (a wrong twin lowers it and the hop is redone)
                         uint64_t mm = 0;           // executed match lanes
                         int      eL = 0;           // end lane of the last executed match
                         uint64_t E = 0;            // executed lanes (probes + inserts)
@@ -460,34 +459,36 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         LV(int, stA); LV(int, hasPm);
                         for (;;) {
                             const unsigned long long th0 = STAT_NOW(); (void)th0;
-                            const uint64_t hitsS = (S >= 64) ? hits : (hits & ((1ull << S) - 1));
-                            LV(int, nextHit);
-                            LANES({
-                                const uint64_t ah = (eLane[I_] < 64) ? (hitsS >> eLane[I_]) : 0;
-                                nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
-                            })
+                            LV(int, nextHit);      // first recorded match at or after the end of the match that starts here (64: none)
+                            {
+                                const uint64_t hitsL = hits;
+                                LANES({
+                                    const uint64_t ah = (eLane[I_] < 64) ? (hitsL >> eLane[I_]) : 0;
+                                    nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
+                                })
+                            }
                             mm = 0; eL = 0; finished = false;
                             const unsigned long long th1 = STAT_NOW(); (void)th1;
                             STAT(S_DBATCH, th1 - th0);
                             int w = 64;
-                            if (cur0 < S) { const uint64_t hm = hitsS & (~0ull << cur0); if (hm) w = ctz64(hm); }
-                            if (w < S && w <= lim0) {
-                                // Hops come four to a branch (a taken branch costs more than the hop): once the walk has run
-                                // past S the remaining steps of a group change nothing (nextHit[w] >= eLane[w] >= S ends it).
+                            if (cur0 < 64) { const uint64_t hm = hits & (~0ull << cur0); if (hm) w = ctz64(hm); }
+                            if (w < 64 && w <= lim0) {
+                                // Hops come four to a branch (a taken branch costs more than the hop).  A hop is: mark the lane,
+                                // fetch its successor.  Once the walk has ended (w == 64) the remaining hops of a group only
+                                // touch bit 0 of the mask, which no hop but the very first can legitimately set.
                                 // Matches longer than the speculative window are not known to the hop: it walks through them
                                 // as if they ended there, and the first one it touched is put right afterwards.
                                 for (;;) {
+                                    const uint64_t low = (mm & 1) | (w == 0 ? 1ull : 0ull);
                                     do {
                                         STAT(S_WALKITER, 1);
                                         for (int u = 0; u < 4; ++u) {
-                                            const bool go = w < S;
-                                            const int  wl = w & 63;
-                                            const int  e1 = RL(eLane, wl), n1 = RL(nextHit, wl);
-                                            mm |= go ? (1ull << wl) : 0ull;
-                                            eL = go ? e1 : eL;
-                                            w  = go ? n1 : w;
+                                            const int n1 = RL(nextHit, w & 63);
+                                            mm |= 1ull << (w & 63);
+                                            w = (w < 64) ? n1 : 64;
                                         }
-                                    } while (w < S);
+                                    } while (w < 64);
+                                    mm = (mm & ~1ull) | low;
                                     const uint64_t sp = mm & specialLeft;
                                     if (!sp) break;
                                     const int ws = ctz64(sp);
@@ -496,18 +497,19 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                     int mc0 = (int)RL(fwd, ws);
                                     if (mc0 == 16) { STAT(S_SAT, 1); mc0 += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); WL(fwd, ws, mc0); }
                                     specialLeft &= ~(1ull << ws);
-                                    eL = ws + kMinMatch + mc0;
-                                    WL(eLane, ws, eL);
-                                    if (base + eL >= lastProbe) { finished = true; break; }   // lz4.c:1233 (only a long match gets there)
-                                    const uint64_t hm = (eL < 64) ? (hitsS & (~0ull << eL)) : 0;
+                                    const int e1 = ws + kMinMatch + mc0;
+                                    WL(eLane, ws, e1);
+                                    if (base + e1 >= lastProbe) { finished = true; break; }   // lz4.c:1233 (only a long match gets there)
+                                    const uint64_t hm = (e1 < 64) ? (hits & (~0ull << e1)) : 0;
                                     w = hm ? ctz64(hm) : 64;
-                                    if (w >= S) break;
+                                    if (w >= 64) break;
                                 }
+                                eL = RL(eLane, 63 - __builtin_clzll(mm));       // mm != 0 here: the first hop always marks
                             }
                             // ---- 3. which lanes did the sequential parser execute
                             const unsigned long long th2 = STAT_NOW(); (void)th2;
                             STAT(S_DMEMB, th2 - th1);
-                            Send = mm ? S : min_(S, lim0 + 1);
+                            Send = mm ? 64 : min_(64, lim0 + 1);
                             const uint64_t mmL = mm; const int SendL = Send;
                             // end of the last executed match below each lane: ends grow along the walk, so an exclusive
                             // prefix maximum over the match lanes (DPP, no LDS round trip) is that value
