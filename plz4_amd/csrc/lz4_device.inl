@@ -306,13 +306,18 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
         uint64_t pMm = 0; int pBase = 0, pAnchor0 = 0, pCur0 = 0; bool pRe0 = false;
         LV(int, pFwd); LV(int, pBck); LV(uint32_t, pR); LV(uint32_t, pLit8); LV(int, pStA); LV(int, pHasPm);
         LANES({ pFwd[I_] = 0; pBck[I_] = 0; pR[I_] = 0; pLit8[I_] = 0; pStA[I_] = 0; pHasPm[I_] = 0; })
-        // ---- 4. emit every recorded sequence of the pending batch at once.  False: liblz4 would return 0 (limitedOutput).
-        auto flush_emit = [&]() -> bool {
+        // ---- 4. emit every recorded sequence of the pending batch at once, in two halves: emit_compute works out where
+        // everything goes (no stores; false: liblz4 would return 0, limitedOutput), emit_store issues the stores.  Between
+        // the two the grid batch waits for its candidate bytes: with the stores behind that wait, it is a wait for those loads
+        // only (the count of younger memory operations is fixed), not for whatever the writer has just stored.
+        uint64_t sMm = 0; int sWin = 0, mlDst = 0, mlSrc = 0, mlLen = 0;
+        LV(int, lit); LV(int, mcT); LV(int, extL); LV(int, extM); LV(int, tok); LV(int, litAt);
+        LANES({ lit[I_] = 0; mcT[I_] = 0; extL[I_] = 0; extM[I_] = 0; tok[I_] = 0; litAt[I_] = -1; })
+        auto emit_compute = [&]() -> bool {
             if (!pMm) return true;
             const uint64_t mm = pMm; const int base = pBase; const int anchor0 = pAnchor0; const int cur0 = pCur0; const bool re0 = pRe0;
             pMm = 0;
-            LV(int, anc); LV(int, lit); LV(int, mcT); LV(int, extL); LV(int, extM); LV(int, size); LV(int, tok);
-            LV(int, pS); LV(int, litDst);
+            LV(int, anc); LV(int, size); LV(int, pS); LV(int, litDst);
             LANES({ anc[I_] = pHasPm[I_] ? base + pStA[I_] : anchor0; })
             {   // catch-up that may go past the 4 speculative bytes (rare): finish it now that the anchors are final
                 const uint64_t mmB = mm;
@@ -334,7 +339,6 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                 extL[I_] = lit[I_] >= 15 ? (lit[I_] - 15) / 255 + 1 : 0;
                 extM[I_] = mcT[I_] >= 15 ? (mcT[I_] - 15) / 255 + 1 : 0;
                 size[I_] = 1 + extL[I_] + lit[I_] + 2 + extM[I_];
-                tok[I_]  = 0;
             })
             const uint64_t mmL = mm;
             {   // output cursor per sequence, in order: a prefix sum over the match lanes
@@ -354,8 +358,29 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                      ((int64_t)tok[I_] + 1 + extL[I_] + lit[I_] + 2 + (1 + kLastLiterals) + (mcT[I_] + 240) / 255 > cap)));
                 if (over) return false;
             }
+            // literals: every lane looks up the next recorded match at or after it
+            LANES({ litDst[I_] = tok[I_] + 1 + extL[I_]; })
             LANES({
-                litDst[I_] = tok[I_] + 1 + extL[I_];
+                const uint64_t ahead = mmL >> LANE;
+                const int m = ahead ? LANE + ctz64(ahead) : LANE;   // all lanes take part in the exchange
+                const int a = SHFL(anc, m), pe = SHFL(pS, m), ld = SHFL(litDst, m);
+                const int q = base + LANE;
+                litAt[I_] = (ahead && q >= a && q < pe) ? ld + (q - a) : -1;
+            })
+            {   // the part of the first run that lies before this window comes from memory
+                const int w0 = ctz64(mm);
+                const int a0 = RL(anc, w0);
+                mlLen = 0;
+                if (a0 < base) { STAT(S_MEMLIT, 1); mlDst = RL(litDst, w0); mlSrc = a0; mlLen = min_(RL(lit, w0), base - a0); }
+            }
+            sMm = mm; sWin = base;
+            return true;
+        };
+        auto emit_store = [&]() {
+            if (!sMm) return;
+            const uint64_t mmL = sMm; const int base = sWin;
+            sMm = 0;
+            LANES({
                 if ((mmL >> LANE) & 1) {
                     const int t = tok[I_];
                     dst[t] = (uint8_t)((min_(lit[I_], 15) << 4) | min_(mcT[I_], 15));
@@ -366,22 +391,11 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                     o += 2;
                     if (extM[I_]) { int rest = mcT[I_] - 15; for (; rest >= 255; rest -= 255) dst[o++] = 255; dst[o++] = (uint8_t)rest; }
                 }
+                if (litAt[I_] >= 0) dst[litAt[I_]] = (uint8_t)pLit8[I_];
             })
-            // literals: every lane looks up the next recorded match at or after it
-            LANES({
-                const uint64_t ahead = mmL >> LANE;
-                const int m = ahead ? LANE + ctz64(ahead) : LANE;   // all lanes take part in the exchange
-                const int a = SHFL(anc, m), pe = SHFL(pS, m), ld = SHFL(litDst, m);
-                const int q = base + LANE;
-                if (ahead && q >= a && q < pe) dst[ld + (q - a)] = (uint8_t)pLit8[I_];
-            })
-            {   // the part of the first run that lies before this window comes from memory
-                const int w0 = ctz64(mm);
-                const int a0 = RL(anc, w0);
-                if (a0 < base) { STAT(S_MEMLIT, 1); wave_copy(dst + RL(litDst, w0), src + a0, min_(RL(lit, w0), base - a0)); }
-            }
-            return true;
+            if (mlLen) wave_copy(dst + mlDst, src + mlSrc, mlLen);
         };
+        auto flush_emit = [&]() -> bool { if (!emit_compute()) return false; emit_store(); return true; };
 
         for (;;) {
             // ================================================================ GRID batch
@@ -417,8 +431,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         if (base + 160 <= n) Pn[I_] = load_win24<false>(src, q + 64);   // request the next window now, use it next batch
                     })
                     prefBase = (base + 160 <= n) ? base + 64 : -1;
-                    // the previous batch's sequences are written while those bytes travel
-                    if (!flush_emit()) return 0;
+                    // the previous batch's sequences are worked out while those bytes travel, and stored behind the wait for them
+                    if (!emit_compute()) return 0;
                     LANES({
                         if (act[I_] && cand[I_] && Cw[I_].w[1] == Pc[I_].w[1]) {
                             hit[I_] = 1;
@@ -427,6 +441,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         }
                         eLane[I_] = LANE + kMinMatch + fwd[I_];     // lane index just past a match that starts here
                     })
+                    emit_store();
                     LDS_FENCE();
                     // LDS atomics on one slot are expected to resolve in ascending lane order (then r is the
                     // nearest earlier twin or the pre-batch value).  Any other order shows up as r >= q somewhere.

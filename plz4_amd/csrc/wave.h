@@ -52,7 +52,7 @@ static inline int plz4_emu_step()  { return plz4_emu_descending ? -1 : 1; }
 #define I_             0
 #define LANE           ((int)(threadIdx.x & 63u))
 #define LANES(...)     { __VA_ARGS__ }
-#define BALLOT(c)      ((uint64_t)__ballot((c)))
+#define BALLOT(c)      ((uint64_t)__builtin_amdgcn_ballot_w64((bool)(c)))
 #define RL(x, w)       plz4_readlane((x)[0], (w))
 #define RLF(x, f, w)   plz4_readlane((x)[0].f, (w))
 /* v is evaluated by the whole wave BEFORE the select (it may contain ballots); then v_cmp + v_cndmask */
