@@ -1054,9 +1054,22 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         plain[I_] = simple || coop[I_];
     })
     const uint64_t plainMask = BALLOT(plain[I_]);
+    if (!(plainMask & 1)) return 0;
+    // Follow the token chain through the whole window, four hops to a branch (mark the lane, fetch its successor; a
+    // finished walk only re-marks lane 0, where it started), then cut the chain at the first sequence that is not plain.
     uint64_t members = 0;
-    for (int cur = 0; cur < 64 && ((plainMask >> cur) & 1); cur = RL(nxt, cur)) members |= 1ull << cur;
-    if (!members) return 0;
+    {
+        int cur = 0;
+        do {
+            for (int u = 0; u < 4; ++u) {
+                const int n1 = RL(nxt, cur & 63);
+                members |= 1ull << (cur & 63);
+                cur = (cur < 64) ? min_(n1, 64) : 64;
+            }
+        } while (cur < 64);
+        const uint64_t odd = members & ~plainMask;
+        if (odd) members &= (1ull << ctz64(odd)) - 1;
+    }
 
     // exclusive prefix sum of the members' output lengths -> where each sequence writes
     LV(int, acc); LV(int, outStart); LV(int, sp);
