@@ -449,7 +449,13 @@ bool is_hc_level(int level) { return level >= 2 && level <= 12; }        // ever
 int ensure_hc(plz4hip_ctx* c)
 {
     if (c->d_hc) return PLZ4HIP_OK;
-    const int waves = c->cus * 8;
+    // The HC parsers are one dependent memory access after another: the more waves a CU holds, the more of that latency
+    // is hidden.  Fill every wave slot the register budget allows (workspace: 320 KiB per wave); PLZ4HIP_HC_WAVES_PER_CU
+    // overrides for experiments.
+    int per = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_encode_rec_hc, 64, 0) != hipSuccess || per < 1) per = 8;
+    if (const char* v = getenv("PLZ4HIP_HC_WAVES_PER_CU")) { const int w = atoi(v); if (w >= 1 && w <= per) per = w; }
+    const int waves = c->cus * per;
     if (hipMalloc((void**)&c->d_hc, (size_t)waves * kHcWorkBytes) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "HC workspace");
     c->hcWaves = waves;
     return PLZ4HIP_OK;
