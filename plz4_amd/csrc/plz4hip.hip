@@ -6,7 +6,9 @@
 // uses no LDS and is bounded by the 32-waves/CU limit.  Independent blocks never communicate.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 #include <cstdio>
@@ -339,6 +341,13 @@ __global__ __launch_bounds__(1024) void k_scan(const int32_t* __restrict__ len, 
     if (t == 1023) off[n] = part[1023];
 }
 
+// Bytes to hand back per block of a host call: the result if positive (sizes), nothing for 0 / error codes.
+__global__ __launch_bounds__(256) void k_out_len(const int32_t* __restrict__ res, int32_t* __restrict__ len, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) len[i] = res[i] > 0 ? res[i] : 0;
+}
+
 // Record mover: dst + dstOff[i] <- src + (srcOff ? srcOff[i] : i*stride), len[i] bytes.  Compaction of the staging
 // area into the frame body is the srcOff == nullptr case.  grid = (n, slices); 256 threads move 16 bytes each per
 // step (unaligned on both sides is fine on gfx950: global_load/store_dwordx4).
@@ -370,9 +379,10 @@ struct plz4hip_ctx {
     int          qslot = 0;
     int          cus = 0;
     int          encWaves = 0, decWaves = 0;
-    // host-API staging (grown on demand)
-    uint8_t*     h_pin = nullptr;  size_t h_cap = 0;
-    uint8_t*     d_buf = nullptr;  size_t d_cap = 0;
+    // host-API staging (grown on demand): a ring of chunks in flight, each with pinned host memory, device memory and a stream
+    struct HostSlot { uint8_t* h = nullptr; size_t hcap = 0; uint8_t* d = nullptr; size_t dcap = 0; hipStream_t s = nullptr; };
+    static constexpr int kSlots = 3;
+    HostSlot     slot[kSlots];
     uint8_t*     d_hc = nullptr;   int hcWaves = 0;     // HC workspace, one slot per resident HC wave (allocated on first use)
 };
 
@@ -423,23 +433,41 @@ uint32_t* next_queue(plz4hip_ctx* c, hipStream_t s, hipError_t* e)
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int ensure_staging(plz4hip_ctx* c, size_t hostBytes, size_t devBytes)
+int ensure_slot(plz4hip_ctx* c, int i, size_t hostBytes, size_t devBytes)
 {
-    if (hostBytes > c->h_cap) {
-        if (c->h_pin) hipHostFree(c->h_pin);
-        c->h_pin = nullptr; c->h_cap = 0;
-        const size_t want = round_up(hostBytes + (hostBytes >> 2), 1 << 20);
-        if (hipHostMalloc((void**)&c->h_pin, want, hipHostMallocDefault) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "hipHostMalloc");
-        c->h_cap = want;
+    plz4hip_ctx::HostSlot& sl = c->slot[i];
+    if (!sl.s && hipStreamCreateWithFlags(&sl.s, hipStreamNonBlocking) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipStreamCreate");
+    if (hostBytes > sl.hcap) {
+        if (sl.h) hipHostFree(sl.h);
+        sl.h = nullptr; sl.hcap = 0;
+        const size_t want = round_up(hostBytes + (hostBytes >> 3), 1 << 20);
+        if (hipHostMalloc((void**)&sl.h, want, hipHostMallocDefault) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "hipHostMalloc");
+        sl.hcap = want;
     }
-    if (devBytes > c->d_cap) {
-        if (c->d_buf) hipFree(c->d_buf);
-        c->d_buf = nullptr; c->d_cap = 0;
-        const size_t want = round_up(devBytes + (devBytes >> 2), 1 << 20);
-        if (hipMalloc((void**)&c->d_buf, want) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "hipMalloc");
-        c->d_cap = want;
+    if (devBytes > sl.dcap) {
+        if (sl.d) hipFree(sl.d);
+        sl.d = nullptr; sl.dcap = 0;
+        const size_t want = round_up(devBytes + (devBytes >> 3), 1 << 20);
+        if (hipMalloc((void**)&sl.d, want) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "hipMalloc");
+        sl.dcap = want;
     }
     return PLZ4HIP_OK;
+}
+
+// memcpy of many buffers on a few host threads (one thread cannot feed PCIe); small jobs stay on the caller's thread
+template <class F> void parallel_blocks(int n, size_t totalBytes, F&& fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? (hw < 8 ? hw : 8) : 4);
+    if (totalBytes < ((size_t)8 << 20) || n < 2 || nt < 2) { for (int i = 0; i < n; ++i) fn(i); return; }
+    if (nt > n) nt = n;
+    std::atomic<int> next{0};
+    auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    std::vector<std::thread> th;
+    th.reserve((size_t)nt - 1);
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
 }
 
 int grid_for(int nBlocks, int resident) { return nBlocks < resident ? nBlocks : resident; }
@@ -530,8 +558,11 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
     if (c->d_queues) hipFree(c->d_queues);
-    if (c->h_pin) hipHostFree(c->h_pin);
-    if (c->d_buf) hipFree(c->d_buf);
+    for (auto& sl : c->slot) {
+        if (sl.s) { hipStreamSynchronize(sl.s); hipStreamDestroy(sl.s); }
+        if (sl.h) hipHostFree(sl.h);
+        if (sl.d) hipFree(sl.d);
+    }
     if (c->d_hc) hipFree(c->d_hc);
     delete c;
 }
@@ -663,17 +694,23 @@ int plz4hip_dev_decode_records(plz4hip_ctx* c, const void* body, const int64_t* 
 // ---------------------------------------------------------------------------------------- host-buffer API
 // Staging layout on both sides: [int32 lenA[n]] [int32 lenB[n]] [int32 res[n]] [int32 st[n]] [in blocks @inStride] [out blocks @outStride]
 namespace {
-struct Staging { size_t offA, offB, offRes, offSt, offIn, offOut, total; int64_t inStride, outStride; };
+// Layout of one chunk in a slot (same offsets in the pinned host buffer and in the device buffer):
+//   [srcLen n][dstCap n][result n][status n][outLen n][outOff n+1 (int64)] | inputs at inStride | outputs at outStride
+// and, device only, the outputs once more back to back (compacted) -- that is what travels back over PCIe.
+struct Staging { size_t offA, offB, offRes, offSt, offLen, offOff, offIn, offOut, offPack, total; int64_t inStride, outStride; };
 
 Staging plan(int n, int maxIn, int maxOut)
 {
     Staging s{};
     const size_t arr = round_up((size_t)n * 4, 256);
-    s.offA = 0; s.offB = arr; s.offRes = 2 * arr; s.offSt = 3 * arr; s.offIn = 4 * arr;
+    s.offA = 0; s.offB = arr; s.offRes = 2 * arr; s.offSt = 3 * arr; s.offLen = 4 * arr;
+    s.offOff = 5 * arr;
+    s.offIn = s.offOff + round_up((size_t)(n + 1) * 8, 256);
     s.inStride = (int64_t)round_up((size_t)maxIn + 16, 16);
     s.outStride = (int64_t)round_up((size_t)maxOut + 16, 16);
     s.offOut = s.offIn + (size_t)n * s.inStride;
-    s.total = s.offOut + (size_t)n * s.outStride;
+    s.offPack = s.offOut + (size_t)n * s.outStride;
+    s.total = s.offPack + (size_t)n * s.outStride;
     return s;
 }
 }  // namespace
@@ -687,6 +724,10 @@ struct DictJob {                       // optional dictionary / linked parameter
     int   level = 1;
 };
 
+// Host-buffer entry points.  A call is cut into chunks of at most kChunkBytes (6 GiB; PLZ4HIP_HOST_CHUNK_MB) of staging; up to kSlots chunks are in flight,
+// each on its own stream: while the GPU works on one, the host threads fill the next and empty the previous, H2D / kernel /
+// D2H of different chunks overlap, and kernels of several chunks share the GPU.  Only the bytes produced travel back
+// (outputs are compacted on the device first).  A linked chain (block i needs block i-1) stays one chunk.
 static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3 dec rec,4 xxh*/, int nBlocks,
                       const void* const* src, const int32_t* srcLen, void* const* dst, const int32_t* dstCap,
                       int bsz, int blockChecksum, int32_t* result, int32_t* status, const DictJob* dj = nullptr)
@@ -702,83 +743,129 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     }
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    Staging st = plan(nBlocks, maxIn, maxOut);
-    const size_t offExtra = st.total;                          // [prevTail 64 KiB][window 2 x 64 KiB][windowLen]
-    if (dj && dj->any) st.total += 3 * 65536 + 256;
-    if (int rc = ensure_staging(c, st.total, st.total)) return rc;
-    hipStream_t s = c->stream;
-    int32_t* hA = (int32_t*)(c->h_pin + st.offA);
-    int32_t* hB = (int32_t*)(c->h_pin + st.offB);
-    for (int i = 0; i < nBlocks; ++i) {
-        hA[i] = srcLen[i];
-        hB[i] = (mode == 0 || mode == 1) ? dstCap[i] : 0;
-        if (srcLen[i]) memcpy(c->h_pin + st.offIn + (size_t)i * st.inStride, src[i], (size_t)srcLen[i]);
-    }
-    HIPCHK(c, hipMemcpyAsync(c->d_buf, c->h_pin, st.offIn + (size_t)nBlocks * st.inStride, hipMemcpyHostToDevice, s));
-    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
-    CodecArgs a{};
-    a.src = c->d_buf + st.offIn; a.srcStride = st.inStride; a.srcLen = (const int32_t*)(c->d_buf + st.offA);
-    a.dst = c->d_buf + st.offOut; a.dstStride = st.outStride; a.dstCap = (const int32_t*)(c->d_buf + st.offB);
-    a.result = (int32_t*)(c->d_buf + st.offRes); a.status = (int32_t*)(c->d_buf + st.offSt);
-    a.queue = q; a.nBlocks = nBlocks; a.bsz = bsz; a.blockChecksum = blockChecksum; a.dstCapAll = bsz + 8;
     const bool dictMode = dj && dj->any;
     const bool hcMode = dj && is_hc_level(dj->level);
-    a.dictLen = -1; a.prevTailLen = -1;
-    if (hcMode) { if (int rc = ensure_hc(c)) return rc; a.level = dj->level; a.hcWork = c->d_hc; }
-    if (dictMode) {
-        if (dj->dict) { a.dict = dj->dict->d_bytes; a.dictLen = dj->dict->len; a.dictTable = dj->dict->d_table; }
-        a.linked = dj->linked;
-        if (dj->prevTail && dj->prevTailLen >= 0) {
-            if (dj->prevTailLen > 65536) return fail(c, PLZ4HIP_E_ARG, "prevTail longer than 64 KiB");
-            memcpy(c->h_pin + offExtra, dj->prevTail, (size_t)dj->prevTailLen);
-            HIPCHK(c, hipMemcpyAsync(c->d_buf + offExtra, c->h_pin + offExtra, (size_t)dj->prevTailLen + 16, hipMemcpyHostToDevice, s));
-            a.prevTail = c->d_buf + offExtra; a.prevTailLen = dj->prevTailLen;
+    const bool chained = dictMode && dj->linked;
+    if (hcMode) { if (int rc = ensure_hc(c)) return rc; }
+    if (dictMode && dj->prevTail && dj->prevTailLen > 65536) return fail(c, PLZ4HIP_E_ARG, "prevTail longer than 64 KiB");
+
+    size_t kChunkBytes = (size_t)6 << 30;      // x kSlots in flight: enough blocks for every encoder wave slot at 4 MiB blocks
+    if (const char* v = getenv("PLZ4HIP_HOST_CHUNK_MB")) { const long mb = atol(v); if (mb > 0) kChunkBytes = (size_t)mb << 20; }   // tests: force many chunks
+    int cb = nBlocks;
+    {
+        const Staging one = plan(1, maxIn, maxOut);
+        const size_t per = (size_t)one.inStride + 2 * (size_t)one.outStride;
+        if (!chained && per * (size_t)nBlocks > kChunkBytes) { cb = (int)(kChunkBytes / per); if (cb < 1) cb = 1; }
+    }
+    const int nChunks = (nBlocks + cb - 1) / cb;
+    // HC kernels index one shared workspace by workgroup: never two of them at once
+    const int nSlots = hcMode ? 1 : (nChunks < plz4hip_ctx::kSlots ? nChunks : plz4hip_ctx::kSlots);
+    const Staging st = plan(cb, maxIn, maxOut);
+    const size_t offExtra = st.total;                          // [prevTail 64 KiB][window 2 x 64 KiB][windowLen]
+    const size_t slotBytes = st.total + (dictMode ? 3 * 65536 + 256 : 0);
+    for (int i = 0; i < nSlots; ++i) if (int rc = ensure_slot(c, i, slotBytes, slotBytes)) return rc;
+
+    auto submit = [&](int k) -> int {
+        plz4hip_ctx::HostSlot& sl = c->slot[k % nSlots];
+        const int b0 = k * cb, nb = (nBlocks - b0 < cb) ? nBlocks - b0 : cb;
+        hipStream_t s = sl.s;
+        int32_t* hA = (int32_t*)(sl.h + st.offA);
+        int32_t* hB = (int32_t*)(sl.h + st.offB);
+        size_t inBytes = 0;
+        for (int i = 0; i < nb; ++i) { hA[i] = srcLen[b0 + i]; hB[i] = (mode == 0 || mode == 1) ? dstCap[b0 + i] : 0; inBytes += (size_t)srcLen[b0 + i]; }
+        parallel_blocks(nb, inBytes, [&](int i) {
+            if (srcLen[b0 + i]) memcpy(sl.h + st.offIn + (size_t)i * st.inStride, src[b0 + i], (size_t)srcLen[b0 + i]);
+        });
+        HIPCHK(c, hipMemcpyAsync(sl.d, sl.h, st.offRes, hipMemcpyHostToDevice, s));                                   // srcLen, dstCap
+        HIPCHK(c, hipMemcpyAsync(sl.d + st.offIn, sl.h + st.offIn, (size_t)nb * st.inStride, hipMemcpyHostToDevice, s));
+        hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
+        CodecArgs a{};
+        a.src = sl.d + st.offIn; a.srcStride = st.inStride; a.srcLen = (const int32_t*)(sl.d + st.offA);
+        a.dst = sl.d + st.offOut; a.dstStride = st.outStride; a.dstCap = (const int32_t*)(sl.d + st.offB);
+        a.result = (int32_t*)(sl.d + st.offRes); a.status = (int32_t*)(sl.d + st.offSt);
+        a.queue = q; a.nBlocks = nb; a.bsz = bsz; a.blockChecksum = blockChecksum; a.dstCapAll = bsz + 8;
+        a.dictLen = -1; a.prevTailLen = -1;
+        if (hcMode) { a.level = dj->level; a.hcWork = c->d_hc; }
+        if (dictMode) {
+            if (dj->dict) { a.dict = dj->dict->d_bytes; a.dictLen = dj->dict->len; a.dictTable = dj->dict->d_table; }
+            a.linked = dj->linked;
+            if (dj->prevTail && dj->prevTailLen >= 0) {
+                memcpy(sl.h + offExtra, dj->prevTail, (size_t)dj->prevTailLen);
+                HIPCHK(c, hipMemcpyAsync(sl.d + offExtra, sl.h + offExtra, (size_t)dj->prevTailLen + 16, hipMemcpyHostToDevice, s));
+                a.prevTail = sl.d + offExtra; a.prevTailLen = dj->prevTailLen;
+            }
+            if (dj->window) {
+                memcpy(sl.h + offExtra + 65536, dj->window, 65536);
+                memcpy(sl.h + offExtra + 3 * 65536, dj->windowLen, sizeof(int));
+                HIPCHK(c, hipMemcpyAsync(sl.d + offExtra + 65536, sl.h + offExtra + 65536, 2 * 65536 + 256, hipMemcpyHostToDevice, s));
+                a.window = sl.d + offExtra + 65536; a.windowLen = (int*)(sl.d + offExtra + 3 * 65536);
+            }
         }
-        if (dj->window) {
-            memcpy(c->h_pin + offExtra + 65536, dj->window, 65536);
-            memcpy(c->h_pin + offExtra + 3 * 65536, dj->windowLen, sizeof(int));
-            HIPCHK(c, hipMemcpyAsync(c->d_buf + offExtra + 65536, c->h_pin + offExtra + 65536, 2 * 65536 + 256, hipMemcpyHostToDevice, s));
-            a.window = c->d_buf + offExtra + 65536; a.windowLen = (int*)(c->d_buf + offExtra + 3 * 65536);
+        switch (mode) {
+        case 0: if (hcMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
+                else if (dictMode) hipLaunchKernelGGL(k_encode_raw_dict, dim3(grid_for(nb, c->encWaves)), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL(k_encode_raw, dim3(grid_for(nb, c->encWaves)), dim3(64), 0, s, a); break;
+        case 1: if (dictMode) hipLaunchKernelGGL(k_decode_raw_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a); break;
+        case 2: a.dstCap = nullptr;
+                if (hcMode) hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
+                else if (dictMode) hipLaunchKernelGGL(k_encode_rec_dict, dim3(grid_for(nb, c->encWaves)), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nb, c->encWaves)), dim3(64), 0, s, a); break;
+        case 3: a.dstCap = nullptr;
+                if (dictMode && dj->linked) hipLaunchKernelGGL(k_decode_rec_linked, dim3(1), dim3(64), 0, s, a);
+                else if (dictMode) hipLaunchKernelGGL(k_decode_rec_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
+                else hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(k_xxh32, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s,
+                                   (const uint8_t*)a.src, a.srcStride, a.srcLen, (uint32_t*)a.result, nb, q); break;
         }
+        HIPCHK(c, hipGetLastError());
+        if (mode != 4) {                                       // pack the outputs: sizes -> offsets -> back to back
+            int32_t* dLen = (int32_t*)(sl.d + st.offLen); int64_t* dOff = (int64_t*)(sl.d + st.offOff);
+            hipLaunchKernelGGL(k_out_len, dim3((nb + 255) / 256), dim3(256), 0, s, (const int32_t*)a.result, dLen, nb);
+            hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, (const int32_t*)dLen, dOff, nb);
+            hipLaunchKernelGGL(k_move_records, dim3(nb, move_slices((int)st.outStride)), dim3(256), 0, s,
+                               (const uint8_t*)(sl.d + st.offOut), (const int64_t*)nullptr, st.outStride, (const int32_t*)dLen,
+                               (const int64_t*)dOff, sl.d + st.offPack, (int64_t)nb * st.outStride);
+            HIPCHK(c, hipGetLastError());
+        }
+        // results, status, sizes and offsets now; the packed bytes once their total is known (retire)
+        HIPCHK(c, hipMemcpyAsync(sl.h + st.offRes, sl.d + st.offRes, st.offIn - st.offRes, hipMemcpyDeviceToHost, s));
+        if (dictMode && dj->window)
+            HIPCHK(c, hipMemcpyAsync(sl.h + offExtra + 65536, sl.d + offExtra + 65536, 2 * 65536 + 256, hipMemcpyDeviceToHost, s));
+        return PLZ4HIP_OK;
+    };
+    auto retire = [&](int k) -> int {
+        plz4hip_ctx::HostSlot& sl = c->slot[k % nSlots];
+        const int b0 = k * cb, nb = (nBlocks - b0 < cb) ? nBlocks - b0 : cb;
+        HIPCHK(c, hipStreamSynchronize(sl.s));
+        const int32_t* hRes = (const int32_t*)(sl.h + st.offRes);
+        const int32_t* hSt  = (const int32_t*)(sl.h + st.offSt);
+        const int32_t* hLen = (const int32_t*)(sl.h + st.offLen);
+        const int64_t* hOff = (const int64_t*)(sl.h + st.offOff);
+        if (mode != 4 && hOff[nb] > 0) {
+            HIPCHK(c, hipMemcpyAsync(sl.h + st.offOut, sl.d + st.offPack, (size_t)hOff[nb], hipMemcpyDeviceToHost, sl.s));
+            HIPCHK(c, hipStreamSynchronize(sl.s));
+        }
+        if (dictMode && dj->window) {
+            memcpy(dj->window, sl.h + offExtra + 65536, 65536);
+            memcpy(dj->windowLen, sl.h + offExtra + 3 * 65536, sizeof(int));
+        }
+        for (int i = 0; i < nb; ++i) { result[b0 + i] = hRes[i]; if (status) status[b0 + i] = hSt[i]; }
+        if (mode != 4)
+            parallel_blocks(nb, (size_t)hOff[nb], [&](int i) {
+                if (hLen[i] > 0 && dst[b0 + i]) memcpy(dst[b0 + i], sl.h + st.offOut + (size_t)hOff[i], (size_t)hLen[i]);
+            });
+        return PLZ4HIP_OK;
+    };
+    int rc = PLZ4HIP_OK;
+    int retired = 0;
+    for (int k = 0; k < nChunks && rc == PLZ4HIP_OK; ++k) {
+        if (k >= nSlots) { rc = retire(retired++); if (rc) break; }       // its slot is the one chunk k needs
+        rc = submit(k);
     }
-    switch (mode) {
-    case 0: if (hcMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nBlocks, c->hcWaves)), dim3(64), 0, s, a);
-            else if (dictMode) hipLaunchKernelGGL(k_encode_raw_dict, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL(k_encode_raw, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
-    case 1: if (dictMode) hipLaunchKernelGGL(k_decode_raw_dict, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a); break;
-    case 2: a.dstCap = nullptr;
-            if (hcMode) hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nBlocks, c->hcWaves)), dim3(64), 0, s, a);
-            else if (dictMode) hipLaunchKernelGGL(k_encode_rec_dict, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL(k_encode_rec, dim3(grid_for(nBlocks, c->encWaves)), dim3(64), 0, s, a); break;
-    case 3: a.dstCap = nullptr;
-            if (dictMode && dj->linked) hipLaunchKernelGGL(k_decode_rec_linked, dim3(1), dim3(64), 0, s, a);
-            else if (dictMode) hipLaunchKernelGGL(k_decode_rec_dict, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(k_xxh32, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s,
-                               (const uint8_t*)a.src, a.srcStride, a.srcLen, (uint32_t*)a.result, nBlocks, q); break;
-    }
-    HIPCHK(c, hipGetLastError());
-    // results first, then only as much payload as the largest result needs per block would require a second pass;
-    // copy the output area back in one transfer.
-    HIPCHK(c, hipMemcpyAsync(c->h_pin + st.offRes, c->d_buf + st.offRes, 2 * (st.offSt - st.offRes), hipMemcpyDeviceToHost, s));
-    if (mode != 4)
-        HIPCHK(c, hipMemcpyAsync(c->h_pin + st.offOut, c->d_buf + st.offOut, (size_t)nBlocks * st.outStride, hipMemcpyDeviceToHost, s));
-    if (dictMode && dj->window)
-        HIPCHK(c, hipMemcpyAsync(c->h_pin + offExtra + 65536, c->d_buf + offExtra + 65536, 2 * 65536 + 256, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    if (dictMode && dj->window) {
-        memcpy(dj->window, c->h_pin + offExtra + 65536, 65536);
-        memcpy(dj->windowLen, c->h_pin + offExtra + 3 * 65536, sizeof(int));
-    }
-    const int32_t* hRes = (const int32_t*)(c->h_pin + st.offRes);
-    const int32_t* hSt  = (const int32_t*)(c->h_pin + st.offSt);
-    for (int i = 0; i < nBlocks; ++i) {
-        result[i] = hRes[i];
-        if (status) status[i] = hSt[i];
-        if (mode != 4 && hRes[i] > 0 && dst[i]) memcpy(dst[i], c->h_pin + st.offOut + (size_t)i * st.outStride, (size_t)hRes[i]);
-    }
-    return PLZ4HIP_OK;
+    for (; retired < nChunks && rc == PLZ4HIP_OK; ++retired) rc = retire(retired);
+    if (rc != PLZ4HIP_OK) for (int i = 0; i < nSlots; ++i) if (c->slot[i].s) hipStreamSynchronize(c->slot[i].s);   // nothing left in flight
+    return rc;
 }
 
 int plz4hip_compress_batch(plz4hip_ctx* c, int nBlocks, const void* const* src, const int32_t* srcLen,

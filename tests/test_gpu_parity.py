@@ -209,3 +209,32 @@ def test_gpu_dev_pipeline(orc, eng):
     assert int(d_st.abs().sum().item()) == 0
     assert int(d_res.sum().item()) == data.size
     assert np.array_equal(d_out[:data.size].cpu().numpy(), data)
+
+
+def test_gpu_host_calls_in_many_chunks(orc, monkeypatch):
+    """The host-buffer entry points cut a large call into chunks that overlap on the GPU; a tiny chunk size forces many
+    chunks (and the slot ring to wrap) on a small input: results must not depend on it."""
+    from plz4_amd._native import Engine
+    monkeypatch.setenv("PLZ4HIP_HOST_CHUNK_MB", "1")
+    e = Engine(0)
+    bsz = 64 << 10
+    data = synth.make("T", 45 * bsz + 777, bsz)
+    srcs = [data[o:o + bsz] for o in range(0, data.size, bsz)] + [np.zeros(0, dtype=np.uint8), np.frombuffer(b"hello", dtype=np.uint8)]
+    srcs.insert(7, synth.make("R", bsz, bsz))                         # a stored-raw block in the middle
+    recs = e.encode_records(srcs, bsz, True)
+    for s, r in zip(srcs, recs):
+        assert np.array_equal(r, orc.block_record(s, bsz, True)), s.size
+    res, st, outs = e.decode_records([np.ascontiguousarray(r) for r in recs], bsz, True)
+    for s, r, k, o in zip(srcs, res, st, outs):
+        assert int(k) == 0 and int(r) == s.size and np.array_equal(o, s)
+    caps = [orc.bound(s.size) if i % 3 else max(s.size // 2, 1) for i, s in enumerate(srcs)]
+    res, outs = e.compress_batch(srcs, caps)
+    for s, cap, r, o in zip(srcs, caps, res, outs):
+        want_n, want = orc.compress_fast(s, cap)
+        assert int(r) == want_n and (want_n == 0 or np.array_equal(o, want[:want_n])), (s.size, cap)
+    comp = [o for r, o in zip(res, outs) if int(r) > 0]
+    plain = [s for r, s in zip(res, srcs) if int(r) > 0]
+    res2, outs2 = e.decompress_batch([np.ascontiguousarray(x) for x in comp], [p.size for p in plain])
+    for p, r, o in zip(plain, res2, outs2):
+        assert int(r) == p.size and np.array_equal(o, p)
+    e.close()
