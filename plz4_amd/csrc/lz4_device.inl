@@ -1024,8 +1024,13 @@ DEV int64_t read_more_len(const uint8_t* src, int* ip, int ilimit, bool initialC
 // the ends of the block -- is left to the exact sequential step of
 // wave_decode_block, which also owns liblz4's accept/reject rules.  Returns the number of sequences decoded.
 // Caller guarantees ip0 + 160 <= iend and op0 + 1088 <= oend (the reference is in its fast loop there).
+// kLds: the batch's output is assembled in `lb`, kDecLdsBytes of LDS owned by this wave (the last kDecTail bytes already
+// written, then up to 1024 new ones), and stored to memory in one coalesced sweep.  Near matches then read LDS instead of
+// waiting a memory round trip per dependency round; `tailAt` is the output position the LDS tail is valid for.
+enum : int { kDecTail = 32, kDecLdsBytes = kDecTail + 1024 + 64 };
+template <bool kLds>
 DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int* ipp, int64_t* opp,
-                                LVREF(v16u_t, win), int* winIp)
+                                LVREF(v16u_t, win), int* winIp, uint8_t* lb = nullptr, int64_t* tailAt = nullptr)
 {
     const int ip0 = *ipp; const int64_t op0 = *opp;
     // every lane holds the 16 input bytes from its window position on; normally requested by the previous batch
@@ -1083,7 +1088,9 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         })
         // a source before the start of the output is the sequential step's business (error, or a dictionary);
         // and the batch's output stays inside the room the caller checked
-        const uint64_t stop = BALLOT(((mL >> LANE) & 1) && (sp[I_] < 0 || acc[I_] > 1024));
+        // (LDS staging: a long match whose source starts before the staged tail and runs into this batch's output as well)
+        const uint64_t stop = BALLOT(((mL >> LANE) & 1) && (sp[I_] < 0 || acc[I_] > 1024 ||
+                                     (kLds && coop[I_] && sp[I_] < op0 - kDecTail && (int64_t)sp[I_] + ml[I_] > op0)));
         if (stop) members &= (1ull << ctz64(stop)) - 1;
     }
     if (!members) return 0;
@@ -1097,6 +1104,81 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
     // A "near" source may contain bytes this batch produces; those go in dependency order below.
     const uint64_t coopM = mL & BALLOT(coop[I_]);
     const uint64_t far = mL & ~coopM & BALLOT((int64_t)sp[I_] + ml[I_] <= op0);
+    if (kLds) {
+        const int total = RL(acc, last);                       // bytes this batch produces
+        auto put_match = [&](uint8_t* d, const v16u_t& a, uint32_t b, int rem) {
+            const uint64_t lo = (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), hi = (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32);
+            uint64_t cur;
+            if (rem >= 16)     { st64u(d, lo); st64u(d + 8, hi); d += 16; rem -= 16; cur = b; }
+            else if (rem >= 8) { st64u(d, lo); d += 8; rem -= 8; cur = hi; }
+            else cur = lo;
+            if (rem & 4) { st32u(d, (uint32_t)cur); d += 4; cur >>= 32; }
+            if (rem & 2) { st16u(d, (uint16_t)cur); d += 2; cur >>= 16; }
+            if (rem & 1) { *d = (uint8_t)cur; }
+        };
+        // far matches: their bytes are requested from memory first ...
+        LV(v16u_t, fa); LV(uint32_t, fb);
+        LANES({
+            fb[I_] = 0; fa[I_].w[0] = 0; fa[I_].w[1] = 0; fa[I_].w[2] = 0; fa[I_].w[3] = 0;
+            if ((far >> LANE) & 1) { fa[I_] = *(const v16u_t*)(dst + sp[I_]); fb[I_] = ld16u(dst + sp[I_] + 16); }
+        })
+        // ... the tail of what is already written, if LDS does not hold it (after a sequential step)
+        if (*tailAt != op0) {
+            LANES({ if (LANE < kDecTail) { const int64_t g = op0 - kDecTail + LANE; lb[LANE] = g >= 0 ? dst[g] : (uint8_t)0; } })
+        }
+        // literal bytes: every window byte finds the member it follows
+        LANES({
+            const uint64_t upto = mL & ((LANE >= 63) ? ~0ull : ((2ull << LANE) - 1));
+            const int m  = upto ? 63 - __builtin_clzll(upto) : LANE;
+            const int os = SHFL(outStart, m), lm = SHFL(ll, m);
+            if (upto && LANE > m && LANE <= m + lm) lb[kDecTail + (os - (int)op0) + (LANE - m - 1)] = (uint8_t)b0[I_];
+        })
+        LANES({ if ((far >> LANE) & 1) put_match(lb + kDecTail + (outStart[I_] - (int)op0) + ll[I_], fa[I_], fb[I_], ml[I_]); })
+        // the rest in dependency order, LDS to LDS (see the memory version below for the rule)
+        for (uint64_t pend = mL & ~far; pend; ) {
+            const int f  = ctz64(pend);
+            const int lo = RL(outStart, f) + RL(ll, f) - (int)op0;           // relative to op0
+            LDS_FENCE();
+            if ((coopM >> f) & 1) {
+                const int len = RL(ml, f); const int64_t s0 = RL(sp, f);
+                if (s0 + len <= op0) { LANES({ for (int i = LANE; i < len; i += 64) lb[kDecTail + lo + i] = dst[s0 + i]; }) }   // older than the window: from memory
+                else wave_copy_match(lb, kDecTail + lo, RL(off, f), len);
+                pend &= pend - 1;
+            } else {
+                const uint64_t go = pend & ~coopM & BALLOT(sp[I_] + ml[I_] - (int)op0 <= lo);
+                LANES({
+                    if ((go >> LANE) & 1) {
+                        const uint8_t* q = lb + kDecTail + (sp[I_] - (int)op0);
+                        v16u_t a; const uint64_t q0 = ld64u(q), q1 = ld64u(q + 8);
+                        a.w[0] = (uint32_t)q0; a.w[1] = (uint32_t)(q0 >> 32); a.w[2] = (uint32_t)q1; a.w[3] = (uint32_t)(q1 >> 32);
+                        fa[I_] = a; fb[I_] = ld16u(q + 16);
+                    }
+                })
+                LDS_FENCE();
+                LANES({ if ((go >> LANE) & 1) put_match(lb + kDecTail + (outStart[I_] - (int)op0) + ll[I_], fa[I_], fb[I_], ml[I_]); })
+                pend &= ~go;
+            }
+        }
+        LDS_FENCE();
+        // one sweep to memory: 16 bytes per lane, then the odd bytes; and keep the last kDecTail bytes for the next batch
+        LANES({
+            for (int cpos = LANE * 16; cpos + 16 <= total; cpos += 1024) {
+                v16u_t a; const uint64_t q0 = ld64u(lb + kDecTail + cpos), q1 = ld64u(lb + kDecTail + cpos + 8);
+                a.w[0] = (uint32_t)q0; a.w[1] = (uint32_t)(q0 >> 32); a.w[2] = (uint32_t)q1; a.w[3] = (uint32_t)(q1 >> 32);
+                *(v16u_t*)(dst + op0 + cpos) = a;
+            }
+            const int odd0 = total & ~15;
+            if (LANE < 16 && odd0 + LANE < total) dst[op0 + odd0 + LANE] = lb[kDecTail + odd0 + LANE];
+        })
+        LV(uint32_t, t8);
+        LANES({ t8[I_] = (LANE < kDecTail) ? (uint32_t)lb[total + LANE] : 0u; })
+        LDS_FENCE();
+        LANES({ if (LANE < kDecTail) lb[LANE] = (uint8_t)t8[I_]; })
+        *tailAt = op0 + total;
+        *ipp = ipn;
+        *opp = op0 + total;
+        return __builtin_popcountll(members);
+    }
     auto copy_matches = [&](const uint64_t who) {
         LANES({
             if ((who >> LANE) & 1) {
@@ -1149,8 +1231,9 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
 // different points, so both sets of tests are reproduced (see oracle/plz4_oracle.c for the same shape).
 // With a dictionary (LZ4_decompress_safe_usingDict, lz4.c:2719-2732 -> forceExtDict): matches may start in `dict`
 // (<= 64 KiB, not adjacent to dst) and run on into the block (lz4.c:2166-2196, :2358-2384).
+template <bool kLds = false>
 DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap,
-                          const uint8_t* dict = nullptr, const int dictLen = 0)
+                          const uint8_t* dict = nullptr, const int dictLen = 0, uint8_t* lb = nullptr)
 {
     if (src == nullptr || cap < 0) return -1;
     const bool ext = (dict != nullptr && dictLen > 0);
@@ -1163,6 +1246,7 @@ DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t*
     if (cap == 0) return (n == 1 && UNI(src[0]) == 0) ? 0 : -1;
     if (n == 0) return -1;
     bool fast = (oend - op) >= 64;
+    int64_t tailAt = -1;                          // LDS staging: output position the staged tail belongs to
     LV(v16u_t, win); int winIp = -1;              // the vector path's input window, requested one batch ahead
     LANES({ win[I_].w[0] = 0; win[I_].w[1] = 0; win[I_].w[2] = 0; win[I_].w[3] = 0; })
     STAT_DECL;
@@ -1170,7 +1254,7 @@ DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t*
     for (;;) {
         if (fast && ip + 160 <= iend && op + 1088 <= oend) {
             WAVE_FENCE();
-            const int nm = wave_decode_plain_batch(src, dst, &ip, &op, win, &winIp);
+            const int nm = wave_decode_plain_batch<kLds>(src, dst, &ip, &op, win, &winIp, lb, &tailAt);
             STAT(S_DBATCH, 1); STAT(S_DMEMB, nm);
             if (nm > 0) { WAVE_FENCE(); continue; }
         }

@@ -279,8 +279,9 @@ __global__ __launch_bounds__(64) void k_decode_raw(CodecArgs a)
 
 // FrameReader._read's per-block checks + BlkT.Decompress on the device (blk/frame.go:54-127, blk.go:50-61).
 // Record i starts at src + recOff[i] when recOff is given, else at src + i*srcStride with srcLen[i] bytes.
-__global__ __launch_bounds__(64) void k_decode_rec(CodecArgs a)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_decode_rec(CodecArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t dl[kDecLdsBytes];       // the vector path assembles each batch's output here
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
         const uint8_t* rec    = a.recOff ? a.src + a.recOff[i] : a.src + (int64_t)i * a.srcStride;
         const int64_t  recLen = a.recOff ? a.recOff[i + 1] - a.recOff[i] : (int64_t)a.srcLen[i];
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64) void k_decode_rec(CodecArgs a)
                     if (sz > cap) { st = PLZ4HIP_BLK_SIZE_OVERFLOW; }
                     else { wave_copy(out, rec + 4, sz); r = sz; }
                 } else {
-                    r = wave_decode_block(rec + 4, sz, out, a.dstCapAll);
+                    r = wave_decode_block<true>(rec + 4, sz, out, a.dstCapAll, nullptr, 0, dl);
                     if (r < 0) st = PLZ4HIP_BLK_CORRUPT;
                 }
             }

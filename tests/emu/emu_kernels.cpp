@@ -18,9 +18,18 @@ int emu_encode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
     return plz4::wave_encode_block(src, n, dst, cap, lds);
 }
 
+// Both builds of the decoder's vector path: the LDS-staged one the record kernels run, and the one that copies through
+// memory (dictionary / raw kernels).  They must agree byte for byte; -999999 flags a disagreement.
 int emu_decode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
 {
-    return plz4::wave_decode_block(src, n, dst, cap);
+    static thread_local uint8_t lds[plz4::kDecLdsBytes];
+    const int r1 = plz4::wave_decode_block<true>(src, n, dst, cap, nullptr, 0, lds);
+    uint8_t* alt = (uint8_t*)malloc((size_t)(cap > 0 ? cap : 1) + 64);
+    memset(alt, 0, (size_t)(cap > 0 ? cap : 1) + 64);
+    const int r2 = plz4::wave_decode_block<false>(src, n, alt, cap);
+    const bool same = (r1 == r2) && (r1 <= 0 || memcmp(dst, alt, (size_t)r1) == 0);
+    free(alt);
+    return same ? r1 : -999999;
 }
 
 uint32_t emu_xxh32(const uint8_t* p, int n) { return plz4::wave_xxh32(p, n); }
