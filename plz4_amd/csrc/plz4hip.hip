@@ -2,8 +2,9 @@
 //
 // Launch shape: ONE 64-lane wavefront per LZ4 block, one wavefront per workgroup, persistent waves pulling
 // block indices from a device-side counter (every wave exits when the counter passes nBlocks).  The encoder
-// owns 16 KiB of LDS (liblz4's hash table, lz4.h:695-697) so 10 encoder waves fit a CU's 160 KiB; the decoder
-// uses no LDS and is bounded by the 32-waves/CU limit.  Independent blocks never communicate.
+// owns 16 KiB of LDS (liblz4's hash table, lz4.h:695-697): nine encoder waves per CU; the record decoder stages
+// each batch of output in 1.1 KiB of LDS and is bounded by its registers (24 waves per CU).  Independent blocks
+// never communicate.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
