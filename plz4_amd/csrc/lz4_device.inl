@@ -1036,6 +1036,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
     // every lane holds the 16 input bytes from its window position on; normally requested by the previous batch
     if (*winIp != ip0) { LANES({ win[I_] = *(const v16u_t*)(src + ip0 + LANE); }) }
     LV(uint32_t, b0); LV(int, ll); LV(int, ml); LV(int, off); LV(int, nxt); LV(int, outLen); LV(int, plain); LV(int, coop);
+    LV(int, longLit);
     LANES({
         const uint64_t w0 = (uint64_t)win[I_].w[0] | ((uint64_t)win[I_].w[1] << 32);
         const uint64_t w1 = (uint64_t)win[I_].w[2] | ((uint64_t)win[I_].w[3] << 32);
@@ -1057,7 +1058,41 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         nxt[I_] = offAt + 2 + (lng ? 1 : 0); outLen[I_] = l + mlen;
         coop[I_]  = parse && !simple && o16 >= 1;                       // long or overlapping: one cooperative copy
         plain[I_] = simple || coop[I_];
+        // a long literal run (nibble 15, one extension byte) whose literals still end inside the window: its offset and
+        // match length sit in another lane's registers, fetched below
+        const uint32_t e1 = (uint32_t)((w0 >> 8) & 0xFF);
+        longLit[I_] = (l == 15) && (e1 < 255) && (LANE + 2 + 15 + (int)e1 <= 64);
     })
+    if (BALLOT(longLit[I_])) {
+        // rare (token bytes >= 0xF0): one lane exchange brings the 4 bytes at the offset's position to the sequence's lane
+        LV(uint32_t, w0lo); LV(int, srcLane); LV(uint32_t, got);
+        LANES({
+            w0lo[I_] = win[I_].w[0];
+            const int l = 15 + (int)((win[I_].w[0] >> 8) & 0xFF);
+            const int offAt = LANE + 2 + l;                              // token, extension byte, l literals
+            srcLane[I_] = longLit[I_] ? min_(offAt, 63) : LANE;
+        })
+        LANES({ got[I_] = SHFL(w0lo, srcLane[I_]); })
+        LANES({
+            if (longLit[I_]) {
+                const int l = 15 + (int)((win[I_].w[0] >> 8) & 0xFF);
+                const int offAt = LANE + 2 + l;
+                const uint32_t v = got[I_] >> (8 * (offAt - srcLane[I_]));          // bytes offAt.. of the window (shift 0 or 8)
+                const uint32_t o16 = v & 0xFFFF;
+                const int mn = (int)(b0[I_] & 15);
+                const bool lng = (mn == 15);
+                const uint32_t e = (v >> 16) & 0xFF;
+                const bool have = !lng || e < 255;                                  // the extension byte is byte 2 of those
+                const int mlen = lng ? 19 + (int)e : mn + kMinMatch;
+                const bool simple = have && !lng && o16 >= (uint32_t)mlen;
+                ll[I_] = l | (1 << 16);                                             // bit 16: the literals start one byte later
+                ml[I_] = mlen; off[I_] = (int)o16;
+                nxt[I_] = offAt + 2 + (lng ? 1 : 0); outLen[I_] = l + mlen;
+                coop[I_]  = have && !simple && o16 >= 1;
+                plain[I_] = simple || coop[I_];
+            }
+        })
+    }
     const uint64_t plainMask = BALLOT(plain[I_]);
     if (!(plainMask & 1)) return 0;
     // Follow the token chain through the whole window, four hops to a branch (mark the lane, fetch its successor; a
@@ -1084,7 +1119,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         const uint64_t mL = members;
         LANES({
             outStart[I_] = (int)op0 + acc[I_] - (((mL >> LANE) & 1) ? outLen[I_] : 0);
-            sp[I_]       = outStart[I_] + ll[I_] - off[I_];                     // where the match bytes come from
+            sp[I_]       = outStart[I_] + (ll[I_] & 0xFFFF) - off[I_];                     // where the match bytes come from
         })
         // a source before the start of the output is the sequential step's business (error, or a dictionary);
         // and the batch's output stays inside the room the caller checked
@@ -1130,14 +1165,15 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         LANES({
             const uint64_t upto = mL & ((LANE >= 63) ? ~0ull : ((2ull << LANE) - 1));
             const int m  = upto ? 63 - __builtin_clzll(upto) : LANE;
-            const int os = SHFL(outStart, m), lm = SHFL(ll, m);
-            if (upto && LANE > m && LANE <= m + lm) lb[kDecTail + (os - (int)op0) + (LANE - m - 1)] = (uint8_t)b0[I_];
+            const int os = SHFL(outStart, m), lp = SHFL(ll, m);
+            const int lm = lp & 0xFFFF, m1 = m + (lp >> 16);              // m1: the byte before the first literal
+            if (upto && LANE > m1 && LANE <= m1 + lm) lb[kDecTail + (os - (int)op0) + (LANE - m1 - 1)] = (uint8_t)b0[I_];
         })
-        LANES({ if ((far >> LANE) & 1) put_match(lb + kDecTail + (outStart[I_] - (int)op0) + ll[I_], fa[I_], fb[I_], ml[I_]); })
+        LANES({ if ((far >> LANE) & 1) put_match(lb + kDecTail + (outStart[I_] - (int)op0) + (ll[I_] & 0xFFFF), fa[I_], fb[I_], ml[I_]); })
         // the rest in dependency order, LDS to LDS (see the memory version below for the rule)
         for (uint64_t pend = mL & ~far; pend; ) {
             const int f  = ctz64(pend);
-            const int lo = RL(outStart, f) + RL(ll, f) - (int)op0;           // relative to op0
+            const int lo = RL(outStart, f) + (RL(ll, f) & 0xFFFF) - (int)op0;           // relative to op0
             LDS_FENCE();
             if ((coopM >> f) & 1) {
                 const int len = RL(ml, f); const int64_t s0 = RL(sp, f);
@@ -1155,7 +1191,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
                     }
                 })
                 LDS_FENCE();
-                LANES({ if ((go >> LANE) & 1) put_match(lb + kDecTail + (outStart[I_] - (int)op0) + ll[I_], fa[I_], fb[I_], ml[I_]); })
+                LANES({ if ((go >> LANE) & 1) put_match(lb + kDecTail + (outStart[I_] - (int)op0) + (ll[I_] & 0xFFFF), fa[I_], fb[I_], ml[I_]); })
                 pend &= ~go;
             }
         }
@@ -1183,7 +1219,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         LANES({
             if ((who >> LANE) & 1) {
                 const uint8_t* s = dst + sp[I_];
-                uint8_t*       d = dst + outStart[I_] + ll[I_];
+                uint8_t*       d = dst + outStart[I_] + (ll[I_] & 0xFFFF);
                 const v16u_t a = *(const v16u_t*)s;
                 const uint32_t b = ld16u(s + 16);
                 const uint64_t lo = (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), hi = (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32);
@@ -1202,15 +1238,16 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
     LANES({
         const uint64_t upto = mL & ((LANE >= 63) ? ~0ull : ((2ull << LANE) - 1));
         const int m  = upto ? 63 - __builtin_clzll(upto) : LANE;
-        const int os = SHFL(outStart, m), lm = SHFL(ll, m);
-        if (upto && LANE > m && LANE <= m + lm) dst[os + (LANE - m - 1)] = (uint8_t)b0[I_];
+        const int os = SHFL(outStart, m), lp = SHFL(ll, m);
+        const int lm = lp & 0xFFFF, m1 = m + (lp >> 16);                  // m1: the byte before the first literal
+        if (upto && LANE > m1 && LANE <= m1 + lm) dst[os + (LANE - m1 - 1)] = (uint8_t)b0[I_];
     })
     // the rest in dependency order.  Near matches: a round takes every pending one whose source ends before the first
     // pending match's output (the first one always qualifies: offset >= length), so nothing it reads is still to be
     // written.  Long or overlapping matches: one cooperative copy each, when they come first.
     for (uint64_t pend = mL & ~far; pend; ) {
         const int f  = ctz64(pend);
-        const int lo = RL(outStart, f) + RL(ll, f);
+        const int lo = RL(outStart, f) + (RL(ll, f) & 0xFFFF);
         WAVE_FENCE();
         if ((coopM >> f) & 1) {
             wave_copy_match(dst, lo, RL(off, f), RL(ml, f));
