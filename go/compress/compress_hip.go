@@ -95,6 +95,127 @@ func (hipDecompressor) DecodeRecords(rec, dst [][]byte, bsz int, blockChecksum b
 	return e.DecodeRecords(rec, dst, bsz, blockChecksum)
 }
 
+// DictT is the reference's dictionary holder (compress/dict.go:5-24); here it also owns the device-side context.
+type DictT struct {
+	Data []byte        // the last 64 KiB of the user dictionary
+	dev  *plz4hip.Dict // plz4hip_dict_create(Data), built on first use
+}
+
+func (d *DictT) device(e *plz4hip.Ctx) (*plz4hip.Dict, error) {
+	if d == nil {
+		return nil, nil
+	}
+	if d.dev == nil {
+		dd, err := e.NewDict(d.Data)
+		if err != nil {
+			return nil, err
+		}
+		d.dev = dd
+	}
+	return d.dev, nil
+}
+
+// hipDictCompressor: level 1 with a dictionary and/or linked blocks (indieCompressorDict / linkedCompressor of the reference,
+// compress/indie.go:12-41, compress/linked.go).  Block-at-a-time Compress keeps the previous block's tail itself, the batch
+// form hands the whole window of blocks to the engine (block i is primed with block i-1 on the device).
+type hipDictCompressor struct {
+	linked bool
+	dict   *DictT
+	tail   []byte // linked: last <= 64 KiB of the previous block of this frame; nil before the first block
+}
+
+func (c *hipDictCompressor) EncodeRecords(src, rec [][]byte, bsz int, blockChecksum bool) ([]int, error) {
+	e, err := engine()
+	if err != nil {
+		return nil, err
+	}
+	dd, err := c.dict.device(e)
+	if err != nil {
+		return nil, err
+	}
+	n, err := e.EncodeRecordsEx(src, rec, bsz, blockChecksum, c.linked, dd, c.tail)
+	if err == nil && c.linked && len(src) > 0 {
+		last := src[len(src)-1]
+		if len(last) > 65536 {
+			last = last[len(last)-65536:]
+		}
+		c.tail = append(c.tail[:0], last...)
+	}
+	return n, err
+}
+
+func (c *hipDictCompressor) Compress(src, dst, _ []byte) (int, error) {
+	e, err := engine()
+	if err != nil {
+		return 0, err
+	}
+	dd, err := c.dict.device(e)
+	if err != nil {
+		return 0, err
+	}
+	if c.linked {
+		return 0, errors.New("plz4_hip: linked blocks go through EncodeRecords (the frame writer), not through Compress")
+	}
+	n, err := e.CompressBatchDict([][]byte{src}, [][]byte{dst}, dd)
+	if err != nil {
+		return 0, err
+	}
+	if n[0] == 0 {
+		return 0, errors.Join(zerr.ErrCompress, plz4hip.ErrLz4Compress)
+	}
+	return n[0], nil
+}
+
+type hipDictDecompressor struct {
+	linked bool
+	dict   *DictT
+	window []byte // linked: compress.DictT's sliding 64 KiB
+	wlen   int
+}
+
+func (c *hipDictDecompressor) Decompress(src, dst []byte) (int, error) {
+	e, err := engine()
+	if err != nil {
+		return 0, err
+	}
+	dd, err := c.dict.device(e)
+	if err != nil {
+		return 0, err
+	}
+	if c.linked {
+		return 0, errors.New("plz4_hip: linked blocks go through DecodeRecords (the frame reader), not through Decompress")
+	}
+	n, err := e.DecompressBatchDict([][]byte{src}, [][]byte{dst}, dd)
+	if err != nil {
+		return 0, err
+	}
+	if n[0] < 0 {
+		return 0, errors.Join(zerr.ErrCorrupted, zerr.ErrDecompress, fmt.Errorf("%w: code %d", plz4hip.ErrLz4Decompress, n[0]))
+	}
+	return n[0], nil
+}
+
+func (c *hipDictDecompressor) DecodeRecords(rec, dst [][]byte, bsz int, blockChecksum bool) ([]int, []int, error) {
+	e, err := engine()
+	if err != nil {
+		return nil, nil, err
+	}
+	dd, err := c.dict.device(e)
+	if err != nil {
+		return nil, nil, err
+	}
+	if !c.linked {
+		return e.DecodeRecordsEx(rec, dst, bsz, blockChecksum, false, dd, nil, nil)
+	}
+	if c.window == nil { // the window starts as the dictionary's last 64 KiB (compress/dict.go:43-56)
+		c.window = make([]byte, 65536)
+		if c.dict != nil {
+			c.wlen = copy(c.window, c.dict.Data)
+		}
+	}
+	return e.DecodeRecordsEx(rec, dst, bsz, blockChecksum, true, nil, c.window, &c.wlen)
+}
+
 type CompressorFactory struct {
 	indie bool
 	level LevelT
@@ -106,19 +227,24 @@ func NewCompressorFactory(level LevelT, independent bool, dict *DictT) Compresso
 }
 
 func (f CompressorFactory) NewCompressor() Compressor {
-	// Levels 1..12 are served for independent blocks.  The engine also has level-1 dictionaries and linked blocks
-	// (plz4hip_dict_create, plz4hip_encode_records_ex / decode_records_ex); this thin shim does not bind them yet.
-	if f.level < 1 || f.level > 12 || !f.indie || f.dict != nil {
-		panic("plz4_hip: independent blocks without a dictionary only in this shim; build without the plz4_hip tag for the rest")
+	// Levels 1..12 for independent blocks without a dictionary; level 1 with a dictionary and/or linked blocks.
+	if f.level < 1 || f.level > 12 {
+		panic("plz4_hip: level out of range")
 	}
-	return hipCompressor{level: f.level}
+	if f.indie && f.dict == nil {
+		return hipCompressor{level: f.level}
+	}
+	if f.level != 1 {
+		panic("plz4_hip: HC levels with a dictionary or linked blocks are not built (PLZ4HIP_E_UNSUPPORTED); build without the plz4_hip tag")
+	}
+	return &hipDictCompressor{linked: !f.indie, dict: f.dict}
 }
 
 func NewDecompressor(independent bool, dict *DictT) Decompressor {
-	if !independent || dict != nil {
-		panic("plz4_hip: linked blocks / dictionaries are not bound by this shim yet")
+	if independent && dict == nil {
+		return hipDecompressor{}
 	}
-	return hipDecompressor{}
+	return &hipDictDecompressor{linked: !independent, dict: dict}
 }
 
 func CompressBound(sz int) int { return plz4hip.CompressBound(sz) }

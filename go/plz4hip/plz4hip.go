@@ -160,3 +160,138 @@ func (c *Ctx) DecodeRecords(rec, dst [][]byte, bsz int, blockChecksum bool) (n [
 	}
 	return
 }
+
+// ---- dictionaries and linked blocks (include/plz4hip.h section B'; the counterparts of clz4.DictCtx, StreamIndieCtx,
+// StreamLinkedCtx and DecompressSafeWithDict, clz4.go:96-248).  Level 1 only: HC levels with a dictionary or linked blocks
+// come back as PLZ4HIP_E_UNSUPPORTED.
+
+// Dict is a dictionary context on the device: the last 64 KiB of the user dictionary and its LZ4_loadDictSlow table.
+type Dict struct {
+	c *Ctx
+	p *C.plz4hip_dict
+}
+
+func (c *Ctx) NewDict(dict []byte) (*Dict, error) {
+	var p *C.plz4hip_dict
+	var dp unsafe.Pointer
+	if len(dict) > 0 {
+		dp = unsafe.Pointer(&dict[0])
+	}
+	if rc := C.plz4hip_dict_create(c.p, dp, C.int(len(dict)), &p); rc != C.PLZ4HIP_OK {
+		return nil, c.engineErr(rc)
+	}
+	return &Dict{c: c, p: p}, nil
+}
+
+func (d *Dict) Close() {
+	if d != nil && d.p != nil {
+		C.plz4hip_dict_destroy(d.c.p, d.p)
+		d.p = nil
+	}
+}
+
+func (d *Dict) ptr() *C.plz4hip_dict {
+	if d == nil {
+		return nil
+	}
+	return d.p
+}
+
+// CompressBatchDict == StreamIndieCtx.Compress(src[i], dst[i]) for every i (clz4.go:160-179): independent blocks, one shared dictionary.
+func (c *Ctx) CompressBatchDict(src, dst [][]byte, d *Dict) ([]int, error) {
+	s, o := newBatch(src, false), newBatch(dst, true)
+	defer s.free()
+	defer o.free()
+	res := make([]C.int32_t, len(src))
+	rc := C.plz4hip_compress_batch_dict(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(o.ptrs), &o.lens[0], 1, d.ptr(), &res[0])
+	if rc != C.PLZ4HIP_OK {
+		return nil, c.engineErr(rc)
+	}
+	out := make([]int, len(res))
+	for i, v := range res {
+		out[i] = int(v)
+	}
+	return out, nil
+}
+
+// DecompressBatchDict == clz4.DecompressSafeWithDict(src[i], dst[i], dict) for every i.
+func (c *Ctx) DecompressBatchDict(src, dst [][]byte, d *Dict) ([]int, error) {
+	s, o := newBatch(src, false), newBatch(dst, true)
+	defer s.free()
+	defer o.free()
+	res := make([]C.int32_t, len(src))
+	rc := C.plz4hip_decompress_batch_dict(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(o.ptrs), &o.lens[0], d.ptr(), &res[0])
+	if rc != C.PLZ4HIP_OK {
+		return nil, c.engineErr(rc)
+	}
+	out := make([]int, len(res))
+	for i, v := range res {
+		out[i] = int(v)
+	}
+	return out, nil
+}
+
+// EncodeRecordsEx == blk.CompressToBlk through a StreamIndieCtx (dict) or a StreamLinkedCtx (linked): block i of a linked
+// call is primed with the last 64 KiB of block i-1; prevTail is that window for block 0 when the call continues a frame
+// (nil: block 0 starts the frame, with the dictionary if there is one -- async/writer.go:412-437).
+func (c *Ctx) EncodeRecordsEx(src, rec [][]byte, bsz int, blockChecksum, linked bool, d *Dict, prevTail []byte) ([]int, error) {
+	s, r := newBatch(src, false), newBatch(rec, true)
+	defer s.free()
+	defer r.free()
+	res := make([]C.int32_t, len(src))
+	var tp unsafe.Pointer
+	tl := C.int(-1)
+	if prevTail != nil {
+		tl = C.int(len(prevTail))
+		if len(prevTail) > 0 {
+			tp = unsafe.Pointer(&prevTail[0])
+		}
+	}
+	rc := C.plz4hip_encode_records_ex(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], C.int(bsz), 1, b2i(blockChecksum), b2i(linked),
+		d.ptr(), tp, tl, (**C.void)(r.ptrs), &res[0])
+	if rc != C.PLZ4HIP_OK {
+		return nil, c.engineErr(rc)
+	}
+	out := make([]int, len(res))
+	for i, v := range res {
+		out[i] = int(v)
+	}
+	return out, nil
+}
+
+// DecodeRecordsEx: the decode side.  For a linked frame the records of one call form a chain; window (64 KiB, in/out)
+// and *windowLen carry the sliding dictionary between calls exactly as compress.DictT does (compress/dict.go:43-86),
+// including its rule that a stored block does not move the window.
+func (c *Ctx) DecodeRecordsEx(rec, dst [][]byte, bsz int, blockChecksum, linked bool, d *Dict, window []byte, windowLen *int) (n []int, status []int, err error) {
+	r, o := newBatch(rec, false), newBatch(dst, true)
+	defer r.free()
+	defer o.free()
+	res := make([]C.int32_t, len(rec))
+	st := make([]C.int32_t, len(rec))
+	var wp unsafe.Pointer
+	wl := C.int(0)
+	if window != nil {
+		wp = unsafe.Pointer(&window[0])
+		wl = C.int(*windowLen)
+	}
+	rc := C.plz4hip_decode_records_ex(c.p, C.int(len(rec)), (**C.void)(r.ptrs), &r.lens[0], C.int(bsz), b2i(blockChecksum), b2i(linked),
+		d.ptr(), wp, &wl, (**C.void)(o.ptrs), &res[0], &st[0])
+	if rc != C.PLZ4HIP_OK {
+		return nil, nil, c.engineErr(rc)
+	}
+	if windowLen != nil {
+		*windowLen = int(wl)
+	}
+	n, status = make([]int, len(res)), make([]int, len(res))
+	for i := range res {
+		n[i], status[i] = int(res[i]), int(st[i])
+	}
+	return
+}
+
+func b2i(b bool) C.int {
+	if b {
+		return 1
+	}
+	return 0
+}
