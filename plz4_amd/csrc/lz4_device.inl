@@ -576,6 +576,10 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                             }
                             break;
                         }
+                        // lz4.c:1233: a match that ends at or past the last probe position ends the block.  Decided here, from the
+                        // final walk: the pass that finished a long match may have been redone after a twin repair, and the redo
+                        // sees that match as an ordinary one.
+                        finished = (mm != 0) && (base + eL >= lastProbe);
                         const unsigned long long tg2 = STAT_NOW(); (void)tg2;
                         STAT(S_CYC_WALK, tg2 - tg1);
                         STAT(S_SEQ_GRID, __builtin_popcountll(mm));

@@ -1,0 +1,65 @@
+"""Fuzz for the level-1 encoder: the device source (compiled for the CPU by tests/emu, ascending and descending lane order)
+against the real LZ4_compress_fast in oracle/_ref on inputs above the byU16 limit (so the grid batches run), three
+capacities per input.  Not part of the test-suite (minutes); run from the repo root."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import corpus                      # noqa: E402
+from emulib import Emu             # noqa: E402
+from orclib import Oracle, Ref     # noqa: E402
+from plz4_amd import synth         # noqa: E402
+
+
+def make(rng, it):
+    n = int(rng.integers(66000, 400000))
+    kind = it % 6
+    if kind == 0:
+        return corpus.structured(n, it)
+    if kind == 1:                                    # short periodic runs: twins inside a window, long matches
+        parts, have = [], 0
+        while have < n:
+            pat = rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)
+            parts += [np.tile(pat, int(rng.integers(1, 200))), rng.integers(0, 256, int(rng.integers(0, 30)), dtype=np.uint8)]
+            have += parts[-1].size + parts[-2].size
+        return np.concatenate(parts)[:n].copy()
+    if kind == 2:
+        return rng.integers(0, 3, n, dtype=np.uint8)
+    if kind == 3:
+        return synth.text(n + 1, seed=it)[:n].copy()
+    if kind == 4:                                    # a small vocabulary of 4..9-byte words: dense hash collisions and twins
+        words = [rng.integers(97, 123, int(rng.integers(4, 10)), dtype=np.uint8) for _ in range(int(rng.integers(3, 60)))]
+        out, have = [], 0
+        while have < n:
+            w = words[int(rng.integers(0, len(words)))]; out.append(w); have += w.size
+        return np.concatenate(out)[:n].copy()
+    base = rng.integers(0, 256, max(n // 9, 1), dtype=np.uint8)
+    a = np.tile(base, 10)[:n].copy()
+    a[rng.integers(0, n, n // 40)] = 7
+    return a
+
+
+def main(iters=120, seed=3):
+    emu, ref, orc = Emu(), Ref(), Oracle()
+    rng = np.random.default_rng(seed)
+    bad = tot = 0
+    for it in range(iters):
+        src = make(rng, it)
+        for desc in (False, True):
+            emu.set_descending(desc)
+            for cap in (orc.bound(src.size), src.size, max(src.size // 3, 1)):
+                a, da = ref.compress_fast(src, cap)
+                b, db = emu.compress_fast(src, cap)
+                tot += 1
+                if a != b or not np.array_equal(da, db):
+                    bad += 1; print("MISMATCH", it, it % 6, src.size, cap, desc, a, b)
+    emu.set_descending(False)
+    print("total", tot, "bad", bad)
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(*(int(x) for x in sys.argv[1:])) else 0)
