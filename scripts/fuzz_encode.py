@@ -15,7 +15,7 @@ from plz4_amd import synth         # noqa: E402
 
 
 def make(rng, it):
-    n = int(rng.integers(66000, 400000))
+    n = int(rng.integers(66000, int(os.environ.get("FUZZ_MAXN", "400000"))))
     kind = it % 6
     if kind == 0:
         return corpus.structured(n, it)
@@ -42,6 +42,26 @@ def make(rng, it):
     return a
 
 
+def main_gpu(iters, seed):
+    """The same inputs through the C ABI in one batch per capacity rule, against the real reference."""
+    from plz4_amd._native import Engine
+    ref, orc, eng = Ref(), Oracle(), Engine(0)
+    rng = np.random.default_rng(seed)
+    srcs = [make(rng, it) for it in range(iters)]
+    bad = tot = 0
+    for rule in (lambda n: orc.bound(n), lambda n: n, lambda n: max(n // 3, 1)):
+        caps = [rule(s.size) for s in srcs]
+        res, outs = eng.compress_batch(srcs, caps)
+        for it, (s, cap, r, o) in enumerate(zip(srcs, caps, res, outs)):
+            a, da = ref.compress_fast(s, cap)
+            tot += 1
+            if int(r) != a or not np.array_equal(o, da):
+                bad += 1; print("GPU MISMATCH", it, it % 6, s.size, cap, a, int(r))
+    eng.close()
+    print("total", tot, "bad", bad)
+    return bad
+
+
 def main(iters=120, seed=3):
     emu, ref, orc = Emu(), Ref(), Oracle()
     rng = np.random.default_rng(seed)
@@ -62,4 +82,7 @@ def main(iters=120, seed=3):
 
 
 if __name__ == "__main__":
-    sys.exit(1 if main(*(int(x) for x in sys.argv[1:])) else 0)
+    args = [int(x) for x in sys.argv[1:] if x != "--gpu"]
+    if "--gpu" in sys.argv:
+        sys.exit(1 if main_gpu(*(args + [120, 3][len(args):])) else 0)
+    sys.exit(1 if main(*args) else 0)
