@@ -16,7 +16,20 @@ from plz4_amd import synth         # noqa: E402
 
 def make(rng, it):
     n = int(rng.integers(66000, int(os.environ.get("FUZZ_MAXN", "400000"))))
-    kind = it % 6
+    kind = it % 8
+    if kind == 6:                                    # noise with sparse repeats: long searches, stride > 1, then a match
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        for _ in range(int(rng.integers(1, 60))):
+            ln = int(rng.integers(4, 400)); s0 = int(rng.integers(0, n - ln)); d0 = int(rng.integers(0, n - ln))
+            a[d0:d0 + ln] = a[s0:s0 + ln].copy()
+        return a
+    if kind == 7:                                    # compressible and incompressible stretches taking turns
+        parts, have = [], 0
+        while have < n:
+            ln = int(rng.integers(50, 30000))
+            parts.append(rng.integers(0, 256, ln, dtype=np.uint8) if rng.random() < 0.5 else synth.text(ln + 1, seed=int(rng.integers(1, 1 << 30)))[:ln])
+            have += ln
+        return np.concatenate(parts)[:n].copy()
     if kind == 0:
         return corpus.structured(n, it)
     if kind == 1:                                    # short periodic runs: twins inside a window, long matches
@@ -56,7 +69,7 @@ def main_gpu(iters, seed):
             a, da = ref.compress_fast(s, cap)
             tot += 1
             if int(r) != a or not np.array_equal(o, da):
-                bad += 1; print("GPU MISMATCH", it, it % 6, s.size, cap, a, int(r))
+                bad += 1; print("GPU MISMATCH", it, it % 8, s.size, cap, a, int(r))
     eng.close()
     print("total", tot, "bad", bad)
     return bad
@@ -75,7 +88,7 @@ def main(iters=120, seed=3):
                 b, db = emu.compress_fast(src, cap)
                 tot += 1
                 if a != b or not np.array_equal(da, db):
-                    bad += 1; print("MISMATCH", it, it % 6, src.size, cap, desc, a, b)
+                    bad += 1; print("MISMATCH", it, it % 8, src.size, cap, desc, a, b)
     emu.set_descending(False)
     print("total", tot, "bad", bad)
     return bad
