@@ -50,5 +50,40 @@ def main(iters=400, seed=7):
     return bad
 
 
+def main_gpu(iters=120, seed=7):
+    """The kernels through the C ABI: one batch per level and capacity rule."""
+    from plz4_amd._native import Engine
+    ref, orc, eng = Ref(), Oracle(), Engine(0)
+    rng = np.random.default_rng(seed)
+    srcs = []
+    for it in range(iters):
+        n = int(rng.integers(0, 60000))
+        kind = it % 3
+        if kind == 0:
+            srcs.append(corpus.structured(n, it))
+        elif kind == 1:
+            srcs.append(synth.text(n + 1)[:n].copy())
+        else:
+            pat = rng.integers(0, 256, int(rng.integers(1, 6)), dtype=np.uint8)
+            a = np.tile(pat, n // pat.size + 1)[:n].copy()
+            if n:
+                a[rng.integers(0, n, n // 60)] = 1
+            srcs.append(a)
+    bad = tot = 0
+    for lvl in range(2, 13):
+        for rule in (lambda n: orc.bound(n), lambda n: n, lambda n: max(n // 2, 1)):
+            caps = [rule(s.size) for s in srcs]
+            res, outs = eng.compress_batch(srcs, caps, level=lvl)
+            for it, (s, cap, r, o) in enumerate(zip(srcs, caps, res, outs)):
+                a, da = ref.compress_hc(s, cap, lvl); tot += 1
+                if int(r) != a or not np.array_equal(o, da):
+                    bad += 1; print("GPU MISMATCH", it, s.size, lvl, cap, a, int(r))
+    eng.close()
+    print("total", tot, "bad", bad)
+    return bad
+
+
 if __name__ == "__main__":
+    if "--gpu" in sys.argv:
+        sys.exit(1 if main_gpu(*(int(x) for x in sys.argv[1:] if x != "--gpu")) else 0)
     sys.exit(1 if main(*(int(x) for x in sys.argv[1:])) else 0)
