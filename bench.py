@@ -183,14 +183,16 @@ def main():
         })
     s_enc = torch.cuda.current_stream()
     s_dec = torch.cuda.Stream(device=dev) if NP > 1 else s_enc
-    stream = s_enc.cuda_stream
+    # N > 1: the framed-output gather (RCCL send/recv + the interleave on rank 0) runs on its own stream, next to the decode
+    # of the same records -- the decoder reads the local body and does not wait for the exchange
+    s_gat = torch.cuda.Stream(device=dev) if world > 1 else None
     log("rank %d: %d blocks (%.1f GiB) in %d part(s) ready in %.1fs" % (rank, B, S / 2**30, NP, time.time() - t0))
 
     gather = {}
 
     def scatter(src, src_off, lens, dst_off, n, max_len, dst):
         eng.dev_scatter_records(src.data_ptr(), src_off.data_ptr(), lens.data_ptr(), dst_off.data_ptr(), n, max_len,
-                                dst.data_ptr(), dst.numel(), stream)
+                                dst.data_ptr(), dst.numel(), torch.cuda.current_stream().cuda_stream)
         gather.setdefault("live", []).append((src_off, lens, dst_off))      # keep operands alive until the step ends
 
     def frame_gather(pt):
@@ -211,19 +213,25 @@ def main():
             if e: e[1].record(s_enc)
             eng.dev_compact_records(pt["stage"].data_ptr(), stride, pt["len"].data_ptr(), pt["nb"], pt["off"].data_ptr(),
                                     pt["body"].data_ptr(), pt["body"].numel(), s_enc.cuda_stream)
-            if e: e[2].record(s_enc)
+            packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
+            packed.record(s_enc)
             if world > 1:
-                frame_gather(pt)
-            ready = torch.cuda.Event(enable_timing=False) if e is None else e[3]
-            ready.record(s_enc)
+                s_gat.wait_event(packed)
+                with torch.cuda.stream(s_gat):                 # collectives and the interleave kernels take the current stream
+                    frame_gather(pt)
+                    if e: e[3].record(s_gat)
+            elif e:
+                e[3].record(s_enc)
             if s_dec is not s_enc:
-                s_dec.wait_event(ready)
+                s_dec.wait_event(packed)
             if e: e[4].record(s_dec)
             eng.dev_decode_records(pt["body"].data_ptr(), pt["off"].data_ptr(), pt["nb"], BSZ, True, pt["out"].data_ptr(), BSZ, BSZ,
                                    pt["res"].data_ptr(), pt["st"].data_ptr(), s_dec.cuda_stream)
             if e: e[5].record(s_dec)
         if s_dec is not s_enc:
             done = torch.cuda.Event(); done.record(s_dec); s_enc.wait_event(done)
+        if s_gat is not None:
+            s_enc.wait_stream(s_gat)                           # the step ends when the frame is assembled, too
 
     # ---- correctness gate before any timing: round trip bit-exact, every block status OK, records == oracle
     d_out.zero_()
