@@ -260,7 +260,9 @@ DEV uint64_t lane_range(int lo, int hi)          // bits lo..hi inclusive, 0 <= 
 //         around its candidate, so hit / forward length (<=16 beyond the 4) / backward length (<=4) are known
 //         for all 64 positions at once.  A scalar walk then plays the sequential parser over the window --
 //         usually several sequences per batch -- and the table is patched (atomic-min for positions the
-//         parser skipped, atomic-max for the ones it executed) to exactly the sequential result.
+//         parser skipped, atomic-max for the ones it executed) to exactly the sequential result.  The batch only
+//         records its sequences; they are written one batch later, in the gap between "candidate bytes requested"
+//         and "candidate bytes needed" (emit_compute / emit_store), so the writer hides that memory latency.
 //   GENERIC (everything else: byU16, block head/tail, stride > 1): one lane per probe of the search loop,
 //         closed-form probe positions, plain store + read-back collision detection, one sequence per batch.
 //
