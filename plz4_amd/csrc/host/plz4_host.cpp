@@ -10,6 +10,17 @@
 
 namespace plz4h {
 
+// Byte buffers of the block pipeline: resize() must not zero-fill 4 MiB that is about to be overwritten
+template <class T> struct NoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInit<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a)
+    {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+using Bytes = std::vector<uint8_t, NoInit<uint8_t>>;
+
+
 // ------------------------------------------------------------------------------------------------ errors
 const char* ErrorString(int c)
 {
@@ -170,8 +181,8 @@ class WriterImpl : public Writer {
     Sink& wr; BlockEngine& eng; Options o;
     const int  bsz;
     const bool sync;                         // NParallel == 0 (sync/writer.go); else async/writer.go semantics
-    std::vector<uint8_t> cur; size_t curLen = 0;            // srcBlk / srcOff
-    std::deque<std::vector<uint8_t>> queue;                 // blocks handed to the "workers", not yet emitted
+    Bytes cur; size_t curLen = 0;            // srcBlk / srcOff
+    std::deque<Bytes> queue;                 // blocks handed to the "workers", not yet emitted
     bool headerDone = false, kicked = false, closed = false, reported = false;
     Error state;                                            // first error wins (async/writer.go:552-555)
     int64_t srcMark = 0, dstMark = 0;
@@ -220,7 +231,7 @@ class WriterImpl : public Writer {
         if (!headerDone) if (Error e = writeHeader()) return e;
         const int n = (int)queue.size();
         std::vector<const void*> src(n); std::vector<int32_t> len(n), rlen(n); std::vector<void*> rec(n);
-        std::vector<std::vector<uint8_t>> recs(n);
+        std::vector<Bytes> recs(n);
         for (int i = 0; i < n; i++) { src[i] = queue[i].data(); len[i] = (int32_t)queue[i].size(); recs[i].resize((size_t)bsz + 8); rec[i] = recs[i].data(); }
         if (Error ee = encode(n, src.data(), len.data(), rec.data(), rlen.data())) { queue.clear(); return ee; }
         Error err;
@@ -234,7 +245,7 @@ class WriterImpl : public Writer {
         queue.clear();
         return err;
     }
-    void enqueue(std::vector<uint8_t>&& b) { if (hashing) hasher.Write(b.data(), b.size()); queue.push_back(std::move(b)); kicked = true; }
+    void enqueue(Bytes&& b) { if (hashing) hasher.Write(b.data(), b.size()); queue.push_back(std::move(b)); kicked = true; }
     Error maybeDrain(bool force) { if (force || (int)queue.size() >= batch_depth(o)) return drain(); return Error(); }
     Error latch(Error e) { if (e && !state) state = e; return state; }
     Error report() { if (state) reported = true; return state; }
@@ -323,13 +334,13 @@ public:
             } else if (!kicked) {
                 // one sub-block payload closed before the pipeline started: _writeSync shortcut
                 cur.resize(curLen);
-                std::vector<uint8_t> only = std::move(cur); cur.clear(); curLen = 0;
+                Bytes only = std::move(cur); cur.clear(); curLen = 0;
                 Error e = supported();
                 if (!e) e = writeHeader();
                 const int64_t hdrSz = dstMark;
                 if (!e) {
                     const void* s = only.data(); int32_t l = (int32_t)only.size(), rl_ = 0;
-                    std::vector<uint8_t> rec((size_t)bsz + 8); void* rp = rec.data();
+                    Bytes rec((size_t)bsz + 8); void* rp = rec.data();
                     e = encode(1, &s, &l, &rp, &rl_);
                     if (!e) e = sinkWrite(rec.data(), (size_t)rl_, nullptr);
                     if (!e) {
@@ -366,9 +377,9 @@ class ReaderImpl : public Reader {
     Xxh32Stream hasher; uint64_t contentSz = 0; uint32_t srcSum = 0;
     int64_t srcPos = 0, dstPos = 0;
     // decoded blocks ready for delivery + the error that follows them
-    struct Out { std::vector<uint8_t> data; int nRead; };
+    struct Out { Bytes data; int nRead; };
     std::deque<Out> ready; Error pendingErr; int pendingRead = 0;
-    std::vector<uint8_t> dstBlk; size_t dstOff = 0;
+    Bytes dstBlk; size_t dstOff = 0;
     bool linked = false; void* dictH = nullptr; bool dictTried = false;
     std::vector<uint8_t> window; int windowLen = 0;            // compress.DictT for linked frames
 
@@ -451,7 +462,7 @@ class ReaderImpl : public Reader {
     void fill()
     {
         const int batch = batch_depth(o);
-        std::vector<std::vector<uint8_t>> recs; std::vector<int> reads;
+        std::vector<Bytes> recs; std::vector<int> reads;
         while ((int)recs.size() < batch && !pendingErr) {
             uint8_t w4[4]; size_t got = 0; int nRead = 0;
             Error e = readFull(w4, 4, &got); nRead += (int)got;
@@ -464,7 +475,7 @@ class ReaderImpl : public Reader {
             const int64_t sz = word & 0x7FFFFFFFu;
             if (sz > bsz) { pendingErr = E(ErrBlockSizeOverflow, true); pendingRead = nRead; break; }
             const size_t total = (size_t)sz + (blkCheck ? 4 : 0);
-            std::vector<uint8_t> rec(4 + total);
+            Bytes rec(4 + total);
             memcpy(rec.data(), w4, 4);
             e = readFull(rec.data() + 4, total, &got); nRead += (int)got;
             if (e) { pendingErr = E(ErrBlockRead); pendingRead = nRead; break; }
@@ -473,7 +484,7 @@ class ReaderImpl : public Reader {
         const int n = (int)recs.size();
         if (!n) return;
         std::vector<const void*> rp(n); std::vector<int32_t> rl_(n), res(n), st(n); std::vector<void*> dp(n);
-        std::vector<std::vector<uint8_t>> outs(n);
+        std::vector<Bytes> outs(n);
         for (int i = 0; i < n; i++) { rp[i] = recs[i].data(); rl_[i] = (int32_t)recs[i].size(); outs[i].resize((size_t)bsz + 8); dp[i] = outs[i].data(); }
         int rc;
         if (linked) rc = eng.DecodeRecordsEx(n, rp.data(), rl_.data(), bsz, blkCheck ? 1 : 0, 1, nullptr, window.data(), &windowLen, dp.data(), res.data(), st.data());

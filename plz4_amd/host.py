@@ -158,7 +158,7 @@ class Writer:
 
     def output(self) -> bytes:
         p = C.c_void_p(); n = self.L.plz4h_writer_output(self.h, C.byref(p))
-        return C.string_at(p, n) if n else b""
+        return bytes((C.c_ubyte * n).from_address(p.value)) if n else b""       # (string_at stops at 2 GiB)
 
     def progress(self):
         p = C.c_void_p(); n = self.L.plz4h_writer_progress(self.h, C.byref(p))
@@ -188,7 +188,7 @@ class Reader:
         n = C.c_int64(0)
         e = self.L.plz4h_reader_write_to(self.h, C.byref(n))
         p = C.c_void_p(); k = self.L.plz4h_reader_output(self.h, C.byref(p))
-        return n.value, (C.string_at(p, k) if k else b""), Err(e)
+        return n.value, (bytes((C.c_ubyte * k).from_address(p.value)) if k else b""), Err(e)
 
     def progress(self):
         p = C.c_void_p(); n = self.L.plz4h_reader_progress(self.h, C.byref(p))
