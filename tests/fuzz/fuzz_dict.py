@@ -1,13 +1,13 @@
 """Fuzz for the dictionary / linked-block encoder and decoder (BASELINE config 5) on the GPU, through the C ABI, against the
 oracle's stream emulation (itself pinned to the real liblz4 in tests/test_oracle_vs_ref.py).  Run from the repo root on a GPU
-box: python scripts/fuzz_dict.py [iters] [seed]."""
+box: python tests/fuzz/fuzz_dict.py [iters] [seed]."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "scripts")]
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "fuzz")]
 import fuzz_encode                 # noqa: E402
 from orclib import Oracle          # noqa: E402
 from plz4_amd._native import Engine  # noqa: E402

@@ -1,4 +1,4 @@
-"""Blocks built sequence by sequence around the boundaries of the decoder's vector path (scripts/fuzz_decode.py): the
+"""Blocks built sequence by sequence around the boundaries of the decoder's vector path (tests/fuzz/fuzz_decode.py): the
 lane-emulated device code on CPU (both builds of the vector path, compared inside tests/emu) and, with -m gpu, the raw and
 the record kernels through the C ABI, all against the oracle / the plaintext the generator kept."""
 import os
@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
 import fuzz_decode  # noqa: E402
 
 

@@ -1,4 +1,4 @@
-"""Inputs that once broke the level-1 encoder, kept as regression tests (found by scripts/fuzz_encode.py against the real
+"""Inputs that once broke the level-1 encoder, kept as regression tests (found by tests/fuzz/fuzz_encode.py against the real
 LZ4_compress_fast).  CPU: the lane-emulated device code; -m gpu: the kernel through the C ABI."""
 import os
 import sys
@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
 import fuzz_encode  # noqa: E402
 
 
