@@ -123,6 +123,12 @@ def cpu_baseline(pool: np.ndarray, seconds: float = 12.0, level: int = 1, check=
 
 
 def main():
+    # Exactly one line goes to stdout: the JSON.  Libraries print to the C-level stdout as well (RCCL writes a version banner
+    # when a communicator comes up), so file descriptor 1 is pointed at stderr for the whole run and the JSON is written to
+    # the original stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -151,7 +157,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # PLZ4_BENCH_FORCE_GATHER=1 runs the N > 1 code path (process group, gather stream, interleave) with a single rank: a
+    # dry run of everything but the peer transfers, for boxes with one GPU
+    multi = world > 1 or bool(os.environ.get("PLZ4_BENCH_FORCE_GATHER"))
+    if multi and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if multi:
         dist.init_process_group("nccl", device_id=dev)
     eng = Engine(local)
 
@@ -193,7 +205,7 @@ def main():
     s_dec = torch.cuda.Stream(device=dev) if NP > 1 else s_enc
     # N > 1: the framed-output gather (RCCL send/recv + the interleave on rank 0) runs on its own stream, next to the decode
     # of the same records -- the decoder reads the local body and does not wait for the exchange
-    s_gat = torch.cuda.Stream(device=dev) if world > 1 else None
+    s_gat = torch.cuda.Stream(device=dev) if multi else None
     log("rank %d: %d blocks (%.1f GiB) in %d part(s) ready in %.1fs" % (rank, B, S / 2**30, NP, time.time() - t0))
 
     gather = {}
@@ -223,7 +235,7 @@ def main():
                                     pt["body"].data_ptr(), pt["body"].numel(), s_enc.cuda_stream)
             packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
             packed.record(s_enc)
-            if world > 1:
+            if multi:
                 s_gat.wait_event(packed)
                 with torch.cuda.stream(s_gat):                 # collectives and the interleave kernels take the current stream
                     frame_gather(pt)
@@ -261,7 +273,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     evs = [[[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in parts] for _ in range(args.steps)]
     torch.cuda.synchronize()
@@ -269,7 +281,7 @@ def main():
     for k in range(args.steps):
         step(evs[k])
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -277,7 +289,7 @@ def main():
     seg = np.array([[sum(e[0].elapsed_time(e[1]) for e in st_), sum(e[1].elapsed_time(e[2]) for e in st_),
                      sum(e[2].elapsed_time(e[3]) for e in st_), sum(e[4].elapsed_time(e[5]) for e in st_)] for st_ in evs])
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
 
@@ -317,8 +329,8 @@ def main():
                 out[key]["traffic"] = t["bytes"]; out[key]["traffic_source"] = t["source"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool, level=args.level, check=check_pairs)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
