@@ -70,6 +70,16 @@ def main_gpu(iters, seed):
             tot += 1
             if int(r) != a or not np.array_equal(o, da):
                 bad += 1; print("GPU MISMATCH", it, it % 8, s.size, cap, a, int(r))
+    # capacities around the size the block really takes: liblz4's limitedOutput tests are conservative, reproduce them exactly
+    sizes = [ref.compress_fast(s, orc.bound(s.size))[0] for s in srcs]
+    for delta in (-9, -1, 0, 1, 4, 5, 6, 12, 13):
+        caps = [max(c + delta, 1) for c in sizes]
+        res, outs = eng.compress_batch(srcs, caps)
+        for it, (s, cap, r, o) in enumerate(zip(srcs, caps, res, outs)):
+            a, da = ref.compress_fast(s, cap)
+            tot += 1
+            if int(r) != a or not np.array_equal(o, da):
+                bad += 1; print("GPU MISMATCH (tight cap)", it, it % 8, s.size, cap, delta, a, int(r))
     eng.close()
     print("total", tot, "bad", bad)
     return bad
