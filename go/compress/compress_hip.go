@@ -115,10 +115,11 @@ func (d *DictT) device(e *plz4hip.Ctx) (*plz4hip.Dict, error) {
 	return d.dev, nil
 }
 
-// hipDictCompressor: level 1 with a dictionary and/or linked blocks (indieCompressorDict / linkedCompressor of the reference,
-// compress/indie.go:12-41, compress/linked.go).  Block-at-a-time Compress keeps the previous block's tail itself, the batch
+// hipDictCompressor: a dictionary and/or linked blocks at any level (indieCompressorDict / indieCompressorDictHC /
+// linkedCompressor / linkedCompressorHC of the reference, compress/indie.go:12-60, compress/linked.go).  Block-at-a-time Compress keeps the previous block's tail itself, the batch
 // form hands the whole window of blocks to the engine (block i is primed with block i-1 on the device).
 type hipDictCompressor struct {
+	level  LevelT
 	linked bool
 	dict   *DictT
 	tail   []byte // linked: last <= 64 KiB of the previous block of this frame; nil before the first block
@@ -133,7 +134,16 @@ func (c *hipDictCompressor) EncodeRecords(src, rec [][]byte, bsz int, blockCheck
 	if err != nil {
 		return nil, err
 	}
-	n, err := e.EncodeRecordsEx(src, rec, bsz, blockChecksum, c.linked, dd, c.tail)
+	n, err := e.EncodeRecordsEx(src, rec, bsz, int(c.level), blockChecksum, c.linked, dd, c.tail)
+	if err == nil && c.linked && c.level > 1 {
+		// linkedCompressorHC.Compress returns liblz4's "does not fit" without joining zerr.ErrCompress (compress/linked.go:47-49),
+		// so blk.CompressToBlk does not store the block raw there (blk/blk.go:75-86): the write fails.  Kept.
+		for i := range rec {
+			if n[i] >= 4 && rec[i][3]&0x80 != 0 {
+				return nil, plz4hip.ErrLz4Compress
+			}
+		}
+	}
 	if err == nil && c.linked && len(src) > 0 {
 		last := src[len(src)-1]
 		if len(last) > 65536 {
@@ -156,7 +166,7 @@ func (c *hipDictCompressor) Compress(src, dst, _ []byte) (int, error) {
 	if c.linked {
 		return 0, errors.New("plz4_hip: linked blocks go through EncodeRecords (the frame writer), not through Compress")
 	}
-	n, err := e.CompressBatchDict([][]byte{src}, [][]byte{dst}, dd)
+	n, err := e.CompressBatchDict([][]byte{src}, [][]byte{dst}, int(c.level), dd)
 	if err != nil {
 		return 0, err
 	}
@@ -227,17 +237,14 @@ func NewCompressorFactory(level LevelT, independent bool, dict *DictT) Compresso
 }
 
 func (f CompressorFactory) NewCompressor() Compressor {
-	// Levels 1..12 for independent blocks without a dictionary; level 1 with a dictionary and/or linked blocks.
+	// Levels 1..12, with or without a dictionary, independent or linked blocks.
 	if f.level < 1 || f.level > 12 {
 		panic("plz4_hip: level out of range")
 	}
 	if f.indie && f.dict == nil {
 		return hipCompressor{level: f.level}
 	}
-	if f.level != 1 {
-		panic("plz4_hip: HC levels with a dictionary or linked blocks are not built (PLZ4HIP_E_UNSUPPORTED); build without the plz4_hip tag")
-	}
-	return &hipDictCompressor{linked: !f.indie, dict: f.dict}
+	return &hipDictCompressor{level: f.level, linked: !f.indie, dict: f.dict}
 }
 
 func NewDecompressor(independent bool, dict *DictT) Decompressor {

@@ -162,10 +162,11 @@ func (c *Ctx) DecodeRecords(rec, dst [][]byte, bsz int, blockChecksum bool) (n [
 }
 
 // ---- dictionaries and linked blocks (include/plz4hip.h section B'; the counterparts of clz4.DictCtx, StreamIndieCtx,
-// StreamLinkedCtx and DecompressSafeWithDict, clz4.go:96-248).  Level 1 only: HC levels with a dictionary or linked blocks
-// come back as PLZ4HIP_E_UNSUPPORTED.
+// StreamLinkedCtx and DecompressSafeWithDict, clz4.go:96-248, and of their HC twins DictCtxHC, StreamCtxHC, StreamLinkedCtxHC,
+// clz4.go:122-147, :181-209, :250-283).  `level` 1..12 as everywhere else.
 
-// Dict is a dictionary context on the device: the last 64 KiB of the user dictionary and its LZ4_loadDictSlow table.
+// Dict is a dictionary context on the device: the last 64 KiB of the user dictionary, its LZ4_loadDictSlow table (level 1) and
+// its LZ4_loadDictHC tables (level 2: lz4mid tables; levels 3..12: hash chain).
 type Dict struct {
 	c *Ctx
 	p *C.plz4hip_dict
@@ -197,13 +198,14 @@ func (d *Dict) ptr() *C.plz4hip_dict {
 	return d.p
 }
 
-// CompressBatchDict == StreamIndieCtx.Compress(src[i], dst[i]) for every i (clz4.go:160-179): independent blocks, one shared dictionary.
-func (c *Ctx) CompressBatchDict(src, dst [][]byte, d *Dict) ([]int, error) {
+// CompressBatchDict == StreamIndieCtx.Compress(src[i], dst[i]) (level 1, clz4.go:160-179) or StreamCtxHC.Compress (levels 2..12,
+// clz4.go:191-209) for every i: independent blocks, one shared dictionary.
+func (c *Ctx) CompressBatchDict(src, dst [][]byte, level int, d *Dict) ([]int, error) {
 	s, o := newBatch(src, false), newBatch(dst, true)
 	defer s.free()
 	defer o.free()
 	res := make([]C.int32_t, len(src))
-	rc := C.plz4hip_compress_batch_dict(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(o.ptrs), &o.lens[0], 1, d.ptr(), &res[0])
+	rc := C.plz4hip_compress_batch_dict(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(o.ptrs), &o.lens[0], C.int(level), d.ptr(), &res[0])
 	if rc != C.PLZ4HIP_OK {
 		return nil, c.engineErr(rc)
 	}
@@ -231,10 +233,11 @@ func (c *Ctx) DecompressBatchDict(src, dst [][]byte, d *Dict) ([]int, error) {
 	return out, nil
 }
 
-// EncodeRecordsEx == blk.CompressToBlk through a StreamIndieCtx (dict) or a StreamLinkedCtx (linked): block i of a linked
+// EncodeRecordsEx == blk.CompressToBlk through a StreamIndieCtx / StreamCtxHC (dict) or a StreamLinkedCtx / StreamLinkedCtxHC
+// (linked), chosen by level as compress.NewCompressorFactory does (compress/compress.go:32-80): block i of a linked
 // call is primed with the last 64 KiB of block i-1; prevTail is that window for block 0 when the call continues a frame
 // (nil: block 0 starts the frame, with the dictionary if there is one -- async/writer.go:412-437).
-func (c *Ctx) EncodeRecordsEx(src, rec [][]byte, bsz int, blockChecksum, linked bool, d *Dict, prevTail []byte) ([]int, error) {
+func (c *Ctx) EncodeRecordsEx(src, rec [][]byte, bsz, level int, blockChecksum, linked bool, d *Dict, prevTail []byte) ([]int, error) {
 	s, r := newBatch(src, false), newBatch(rec, true)
 	defer s.free()
 	defer r.free()
@@ -247,7 +250,7 @@ func (c *Ctx) EncodeRecordsEx(src, rec [][]byte, bsz int, blockChecksum, linked 
 			tp = unsafe.Pointer(&prevTail[0])
 		}
 	}
-	rc := C.plz4hip_encode_records_ex(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], C.int(bsz), 1, b2i(blockChecksum), b2i(linked),
+	rc := C.plz4hip_encode_records_ex(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], C.int(bsz), C.int(level), b2i(blockChecksum), b2i(linked),
 		d.ptr(), tp, tl, (**C.void)(r.ptrs), &res[0])
 	if rc != C.PLZ4HIP_OK {
 		return nil, c.engineErr(rc)

@@ -103,13 +103,21 @@ int plz4hip_decode_records(plz4hip_ctx* ctx, int nBlocks,
                            void* const* dst, int32_t* result, int32_t* status);
 
 /* ---------------------------------------------------------------------------------------------------------
- * B'. Dictionaries and linked blocks (level 1; SURVEY.md §8a-11, BASELINE config 5).
- *    plz4hip_dict == clz4.DictCtx (clz4.go:96-120: private copy of the last 64 KiB + the LZ4_loadDictSlow table).
- *    *_batch_dict : clz4.StreamIndieCtx.Compress (clz4.go:160-179) / clz4.DecompressSafeWithDict (clz4.go:62-78) per block,
- *                   i.e. CompressBlock/DecompressBlock with WithBlockDictionary (plz4_block.go:48-53).
+ * B'. Dictionaries and linked blocks (levels 1..12; SURVEY.md §8a-11, BASELINE config 5).
+ *    plz4hip_dict == clz4.DictCtx + clz4.DictCtxHC (clz4.go:96-147: private copy of the last 64 KiB, the LZ4_loadDictSlow
+ *                   table for level 1, the LZ4_loadDictHC tables for level 2 (lz4mid) and for levels 3..12 (hash chain)).
+ *    *_batch_dict : level 1: clz4.StreamIndieCtx.Compress (clz4.go:160-179); levels 2..12: clz4.StreamCtxHC.Compress
+ *                   (clz4.go:191-209 -> LZ4_compress_HC_continue under an attached dictionary, lz4hc.c:1438-1461);
+ *                   clz4.DecompressSafeWithDict (clz4.go:62-78) per block -- i.e. CompressBlock/DecompressBlock with
+ *                   WithBlockDictionary (plz4_block.go:48-53).
  *    encode_records_ex: `dict` = WithDictionary; `linked` = WithBlockLinked: block i>0 is primed with the last <= 64 KiB of
- *                   src[i-1] (async/writer.go:412-437 -> LZ4_loadDict, clz4.go:224-241); block 0 with prevTail when the
- *                   batch continues a frame (prevTail == NULL: block 0 starts the frame and uses `dict`, if any).
+ *                   src[i-1] (async/writer.go:412-437 -> LZ4_loadDict, clz4.go:224-241; levels 2..12: LZ4_loadDictHC,
+ *                   clz4.go:262-283); block 0 with prevTail when the batch continues a frame (prevTail == NULL: block 0
+ *                   starts the frame and uses `dict`, if any).  As everywhere, a block the encoder cannot fit into bsz
+ *                   bytes comes back as a stored record; NOTE that the reference's linked HC compressor does not: it
+ *                   fails the write instead (compress/linked.go:47-49 returns the error without zerr.ErrCompress, so
+ *                   blk.CompressToBlk takes no fallback) -- a drop-in caller checks the stored bit of rec[i] for
+ *                   linked && level > 1 and reports the error (the host layer and the Go shim do).
  *    decode_records_ex: independent blocks + dict: every block against `dict` (compress/decompress.go:42-58);
  *                   linked: a serial chain over the batch; `window` (64 KiB, caller-owned) / `*windowLen` carry
  *                   compress.DictT (compress/dict.go:5-56) across calls: initialise with the dictionary's last 64 KiB

@@ -210,10 +210,10 @@ class Engine:
     def dict_destroy(self, d):
         self.L.plz4hip_dict_destroy(self.h, d)
 
-    def compress_batch_dict(self, srcs, caps, d):
+    def compress_batch_dict(self, srcs, caps, d, level: int = 1):
         n = len(srcs); lens = _i32([s.size for s in srcs]); capa = _i32(caps)
         dsts = [np.empty(max(int(c), 1), dtype=np.uint8) for c in caps]; res = np.zeros(n, dtype=np.int32)
-        self._chk(self.L.plz4hip_compress_batch_dict(self.h, n, _ptr_array(srcs), _i32p(lens), _ptr_array(dsts), _i32p(capa), 1, d, _i32p(res)))
+        self._chk(self.L.plz4hip_compress_batch_dict(self.h, n, _ptr_array(srcs), _i32p(lens), _ptr_array(dsts), _i32p(capa), level, d, _i32p(res)))
         return res, [x[:max(int(r), 0)] for x, r in zip(dsts, res)]
 
     def decompress_batch_dict(self, srcs, caps, d):
@@ -222,12 +222,12 @@ class Engine:
         self._chk(self.L.plz4hip_decompress_batch_dict(self.h, n, _ptr_array(srcs), _i32p(lens), _ptr_array(dsts), _i32p(capa), d, _i32p(res)))
         return res, [x[:max(int(r), 0)] for x, r in zip(dsts, res)]
 
-    def encode_records_ex(self, srcs, bsz, block_checksum, linked=False, d=None, prev_tail=None):
+    def encode_records_ex(self, srcs, bsz, block_checksum, linked=False, d=None, prev_tail=None, level: int = 1):
         n = len(srcs); lens = _i32([s.size for s in srcs])
         recs = [np.empty(bsz + 8, dtype=np.uint8) for _ in range(n)]; rl = np.zeros(n, dtype=np.int32)
         pt = prev_tail.ctypes.data if (prev_tail is not None and prev_tail.size) else (np.zeros(1, np.uint8).ctypes.data if prev_tail is not None else None)
         self._keep_pt = prev_tail
-        self._chk(self.L.plz4hip_encode_records_ex(self.h, n, _ptr_array(srcs), _i32p(lens), bsz, 1, int(block_checksum), int(linked), d,
+        self._chk(self.L.plz4hip_encode_records_ex(self.h, n, _ptr_array(srcs), _i32p(lens), bsz, level, int(block_checksum), int(linked), d,
                                                    pt, 0 if prev_tail is None else prev_tail.size, _ptr_array(recs), _i32p(rl)))
         return [r[:int(k)] for r, k in zip(recs, rl)]
 

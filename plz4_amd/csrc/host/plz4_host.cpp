@@ -219,8 +219,7 @@ class WriterImpl : public Writer {
     }
     Error supported() const
     {
-        const bool hc = o.Level >= 2 && o.Level <= 12;       // HC levels: independent blocks without a dictionary only, so far
-        if (o.Level != 1 && !(hc && !exMode())) return E(ErrUnsupported);
+        if (o.Level < 1 || o.Level > 12) return E(ErrUnsupported);   // WithLevel clamps to [1,12] (plz4_opts.go:139-149)
         return Error();
     }
     // blk.CompressToBlk x n on the engine, then in-order emission (async/writer.go:284-381 writeLoop)
@@ -235,8 +234,13 @@ class WriterImpl : public Writer {
         for (int i = 0; i < n; i++) { src[i] = queue[i].data(); len[i] = (int32_t)queue[i].size(); recs[i].resize((size_t)bsz + 8); rec[i] = recs[i].data(); }
         if (Error ee = encode(n, src.data(), len.data(), rec.data(), rlen.data())) { queue.clear(); return ee; }
         Error err;
+        // linkedCompressorHC.Compress hands liblz4's "does not fit" back WITHOUT joining zerr.ErrCompress
+        // (compress/linked.go:47-49, unlike every other compressor), so CompressToBlk does not fall back to a stored block
+        // there (blk/blk.go:75-86): a linked frame above level 1 fails at its first incompressible block.  Kept as it is.
+        const bool storedIsFatal = o.BlockLinked && o.Level > 1;
         for (int i = 0; i < n && !err; i++) {
             size_t w = 0;
+            if (storedIsFatal && (recs[i][3] & 0x80)) { err = E(ErrCompress); break; }
             Error e = sinkWrite(recs[i].data(), (size_t)rlen[i], &w);
             progress(srcMark, dstMark);
             srcMark += len[i]; dstMark += (int64_t)w;
@@ -342,6 +346,7 @@ public:
                     const void* s = only.data(); int32_t l = (int32_t)only.size(), rl_ = 0;
                     Bytes rec((size_t)bsz + 8); void* rp = rec.data();
                     e = encode(1, &s, &l, &rp, &rl_);
+                    if (!e && o.BlockLinked && o.Level > 1 && (rec[3] & 0x80)) e = E(ErrCompress);    // see drain(): linked HC has no stored fallback
                     if (!e) e = sinkWrite(rec.data(), (size_t)rl_, nullptr);
                     if (!e) {
                         progress(0, hdrSz);

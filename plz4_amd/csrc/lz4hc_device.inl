@@ -12,8 +12,20 @@
 //
 // Parity first: this round the parser runs as ONE logical thread per block (all 64 lanes of the wave execute the same
 // scalar program on uniform data; loads broadcast, stores coalesce), with its 256 KiB hash/chain tables and the 64 KiB
-// price table in a per-wave HBM workspace.  Only the single-segment case exists here (independent block, no dictionary):
-// lowLimit == dictLimit == 64 KiB, so every "extDict" / "dictCtx" branch of the reference is dead and is not restated.
+// price table in a per-wave HBM workspace.
+//
+// Dictionaries and linked blocks (clz4.StreamCtxHC clz4.go:191-209, StreamLinkedCtxHC :250-283) come in the two
+// shapes LZ4_compress_HC_continue can take under plz4 (lz4hc.c:1438-1461, :1626-1720):
+//   kHcExt  the block has an external segment of <= 64 KiB in front of it: a linked block after LZ4_loadDictHC(previous
+//           tail) + LZ4HC_setExternalDict, or a block > 4 KiB under an attached dictionary (the dictionary context's state is
+//           copied, then setExternalDict).  Both leave the same state: indices 64 KiB.. over the segment, inserted up to its
+//           last 3 bytes (hash chain) or LZ4MID_fillHTable (level 2), the block's prefix starting right behind.  The caller
+//           lays the segment out IMMEDIATELY BEFORE the block in memory, so "position" below counts from the segment's first
+//           byte and every two-segment count of the reference is one count over contiguous bytes; what the reference does
+//           differently for candidates inside the segment is kept (no 2-byte pre-check, back-extension limits, the
+//           protectDictEnd rule, level 2 not matching across the boundary).
+//   kHcCtx  a block <= 4 KiB under an attached dictionary (usingDictCtxHc): own empty tables, and the dictionary context's
+//           tables (read-only, built once per dictionary by hc_prime_dict) searched after the own chain ends.
 // Compiled for the CPU as-is by tests/emu (checked there against the real liblz4 in oracle/_ref).
 #pragma once
 #include "wave.h"
@@ -30,10 +42,20 @@ enum : int { kHcHashEntries = 32768, kHcChainEntries = 65536, kHcOptNum = 4096, 
              kHcWorkBytes = kHcHashEntries * 4 + kHcChainEntries * 2 + (kHcOptNum + kHcTrailing + 1) * 16 };
 static constexpr uint32_t kHcBase = 65536u;                           // LZ4HC_init_internal: first index (lz4hc.c:252-258)
 
+enum : int { kHcNone = 0, kHcExt = 1, kHcCtx = 2 };
+struct HcDict {                 // how a block is primed (see the header comment)
+    int mode;                   // kHcNone / kHcExt / kHcCtx
+    int len;                    // kHcExt: bytes of the segment lying right before the block; kHcCtx: dictionary length
+    const uint8_t*  bytes;      // kHcCtx: the dictionary
+    const uint32_t* hash;       // kHcCtx: the dictionary context's tables (hc_prime_dict over `bytes`)
+    const uint16_t* chain;
+};
 struct HcState {
-    const uint8_t* src; int n;
+    const uint8_t* src;         // first byte of the segment (== the block when there is none); positions count from here
+    int pfx;                    // bytes of the segment: the block's prefix starts at position pfx, index kHcBase + pfx
     HcWork w;
     uint32_t nextToUpdate;
+    HcDict d;
 };
 
 DEV uint32_t hc_hash(const uint8_t* p) { return (ld32u(p) * 2654435761u) >> 17; }          // lz4hc.c:120-122 (15 bits)
@@ -106,8 +128,11 @@ DEV int hc_count_back(const uint8_t* ip, const uint8_t* match, const uint8_t* iM
     return back;
 }
 
-// LZ4HC_InsertAndGetWiderMatch (lz4hc.c:884-1104) for a single prefix segment: `lowLimit` is iLowLimit (how far the match
-// may be extended backwards), `longest` the length to beat, patternAnalysis / chainSwap as in the reference.
+// LZ4HC_protectDictEnd (lz4hc.c:876-879): false for the last 3 indices of the external segment
+DEV bool hc_protect(uint32_t prefixIdx, uint32_t mi) { return (uint32_t)((prefixIdx - 1u) - mi) >= 3u; }
+
+// LZ4HC_InsertAndGetWiderMatch (lz4hc.c:884-1104): `lowLimit` is iLowLimit (how far the match may be extended backwards),
+// `longest` the length to beat, patternAnalysis / chainSwap as in the reference.  Positions count from s.src.
 DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches,
                           bool patternAnalysis, bool chainSwap)
 {
@@ -115,8 +140,11 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
     const uint8_t* const ip = src + pos;
     const uint8_t* const iLow = src + lowLimit;
     const uint8_t* const iHigh = src + highLimit;
+    const uint8_t* const prefixPtr = src + s.pfx;
+    const uint32_t prefixIdx = kHcBase + (uint32_t)s.pfx;
     const uint32_t ipIndex = (uint32_t)pos + kHcBase;
-    const uint32_t lowest = (kHcBase + 65536u > ipIndex) ? kHcBase : ipIndex - 65535u;          // :899-900
+    const bool     within = kHcBase + 65536u > ipIndex;                                         // withinStartDistance, :898
+    const uint32_t lowest = within ? kHcBase : ipIndex - 65535u;                                 // :899
     const int lookBack = pos - lowLimit;
     int offset = 0, sBack = 0;
     int attempts = nbSearches;
@@ -133,13 +161,21 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
         attempts--;
         {
             const uint8_t* const mp = src + (mi - kHcBase);
-            if (ld16u(iLow + longest - 1) == ld16u(mp - lookBack + longest - 1)) {              // :929
-                if (ld32u(mp) == pattern) {
-                    const int back = lookBack ? hc_count_back(ip, mp, iLow, src) : 0;
-                    mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
-                    mlen -= back;
-                    if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
+            if (mi >= prefixIdx) {                                                               // within the prefix, :925-939
+                if (ld16u(iLow + longest - 1) == ld16u(mp - lookBack + longest - 1)) {
+                    if (ld32u(mp) == pattern) {
+                        const int back = lookBack ? hc_count_back(ip, mp, iLow, prefixPtr) : 0;
+                        mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
+                        mlen -= back;
+                        if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
+                    }
                 }
+            } else if (mi <= prefixIdx - 4u && ld32u(mp) == pattern) {                           // within the segment, :940-960
+                // count to the segment's end, then on into the prefix: one count over contiguous bytes
+                mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
+                const int back = lookBack ? hc_count_back(ip, mp, iLow, src) : 0;
+                mlen -= back;
+                if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
             }
         }
         if (chainSwap && mlen == longest) {                                                      // :964-987
@@ -169,28 +205,35 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
                         srcPatternLength = hc_count_pattern(ip + 4, iHigh, pattern) + 4;
                     } else repeat = 1;
                 }
-                if (repeat == 2 && mci >= lowest) {           // LZ4HC_protectDictEnd is always true above the prefix start (:873-876)
+                if (repeat == 2 && mci >= lowest && hc_protect(prefixIdx, mci)) {
                     const uint8_t* const mp = src + (mci - kHcBase);
                     if (ld32u(mp) == pattern) {
+                        // forward to the segment's end and on into the prefix with the rotated pattern (:1009-1013), backwards
+                        // from the prefix into the segment (:1017-1021): the same periodic run over contiguous bytes
                         const size_t fwd = hc_count_pattern(mp + 4, iHigh, pattern) + 4;
                         size_t back = hc_rcount_pattern(mp, src, pattern);
                         {   const uint32_t far = mci - (uint32_t)back;                           // limit to lowestMatchIndex, :1022-1023
                             back = mci - (far > lowest ? far : lowest); }
                         const size_t seg = back + fwd;
                         if (seg >= srcPatternLength && fwd <= srcPatternLength) {
-                            mi = mci + (uint32_t)fwd - (uint32_t)srcPatternLength;               // :1027-1036
+                            const uint32_t nmi = mci + (uint32_t)fwd - (uint32_t)srcPatternLength;   // :1027-1036
+                            mi = hc_protect(prefixIdx, nmi) ? nmi : prefixIdx;
                         } else {
-                            mi = mci - (uint32_t)back;                                           // :1038-1058
-                            if (lookBack == 0) {
-                                const size_t maxML = seg < srcPatternLength ? seg : srcPatternLength;
-                                if ((size_t)longest < maxML) {
-                                    if (ipIndex - mi > 65535u) break;
-                                    longest = (int)maxML;
-                                    offset = (int)(ipIndex - mi);
+                            const uint32_t nmi = mci - (uint32_t)back;                           // :1038-1058
+                            if (!hc_protect(prefixIdx, nmi)) mi = prefixIdx;
+                            else {
+                                mi = nmi;
+                                if (lookBack == 0) {
+                                    const size_t maxML = seg < srcPatternLength ? seg : srcPatternLength;
+                                    if ((size_t)longest < maxML) {
+                                        if (ipIndex - mi > 65535u) break;
+                                        longest = (int)maxML;
+                                        offset = (int)(ipIndex - mi);
+                                    }
+                                    const uint32_t dp = s.w.chain[mi & 0xFFFFu];
+                                    if (dp > mi) break;
+                                    mi -= dp;
                                 }
-                                const uint32_t dp = s.w.chain[mi & 0xFFFFu];
-                                if (dp > mi) break;
-                                mi -= dp;
                             }
                         }
                         continue;
@@ -199,6 +242,24 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
             }
         }
         mi -= s.w.chain[(mi + chainPos) & 0xFFFFu];                                              // :1065
+    }
+    if (s.d.mode == kHcCtx && attempts > 0 && within) {                                          // usingDictCtxHc, :1069-1098
+        const uint32_t dictEnd = kHcBase + (uint32_t)s.d.len;        // the context's end index: its own indices start at 64 KiB
+        uint32_t dmi = s.d.hash[hc_hash(ip)];
+        mi = dmi + lowest - dictEnd;
+        while (ipIndex - mi <= 65535u && attempts--) {
+            const uint8_t* const mp = s.d.bytes + (dmi - kHcBase);
+            if (ld32u(mp) == pattern) {
+                const uint8_t* vLimit = ip + (dictEnd - dmi);
+                if (vLimit > iHigh) vLimit = iHigh;
+                int mlt = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, vLimit);
+                const int back = lookBack ? hc_count_back(ip, mp, iLow, s.d.bytes) : 0;
+                mlt -= back;
+                if (mlt > longest) { longest = mlt; offset = (int)(ipIndex - mi); sBack = back; }
+            }
+            const uint32_t nx = s.d.chain[dmi & 0xFFFFu];
+            dmi -= nx; mi -= nx;
+        }
     }
     HcMatch m; m.len = longest; m.off = offset; m.back = sBack;
     return m;
@@ -273,21 +334,55 @@ DEV void hc_reset_tables(HcWork w)
     for (int i = 0; i < kHcChainEntries; ++i) w.chain[i] = 0;
 }
 
+// Level 2 keeps two 16 K-entry tables inside the HC hash table: 4-byte hashes in the lower half, 7-of-8-byte hashes in the
+// upper half (lz4hc.c:141-151, :532-533).
+DEV uint32_t mid_hash4(const uint8_t* p) { return (ld32u(p) * 2654435761u) >> (32 - 14); }
+DEV uint32_t mid_hash8(const uint8_t* p) { return (uint32_t)(((ld64u(p) << 8) * 58295818150454627ull) >> (64 - 14)); }
+
+// Fresh tables, then what LZ4_loadDictHC leaves over the segment [0, pfx) (lz4hc.c:1626-1653): LZ4MID_fillHTable (:477-503) at
+// level 2, LZ4HC_Insert up to the segment's last 3 bytes otherwise; LZ4HC_setExternalDict (:1660-1678) then resumes
+// referencing at the prefix.  The same state is what a dictionary context carries (clz4.go:122-147), so this also builds the
+// tables of HcDict for kHcCtx (pfx = dictionary length).
+DEV void hc_prime(HcState& s, int level)
+{
+    hc_reset_tables(s.w);
+    s.nextToUpdate = kHcBase;
+    const int size = s.pfx;
+    if (level <= 2) {
+        uint32_t* const h4t = s.w.hash;
+        uint32_t* const h8t = s.w.hash + 16384;
+        if (size > 8) {
+            const uint32_t target = kHcBase + (uint32_t)size - 8u;
+            uint32_t idx = kHcBase;
+            for (; idx < target; idx += 3) {
+                h4t[mid_hash4(s.src + (idx - kHcBase))] = idx;
+                h8t[mid_hash8(s.src + (idx + 1 - kHcBase))] = idx + 1;
+            }
+            idx = (size > 32768 + 8) ? target - 32768u : kHcBase;
+            for (; idx < target; ++idx) h8t[mid_hash8(s.src + (idx - kHcBase))] = idx;
+        }
+    } else if (size >= 4) {
+        hc_insert(s, size - 3);
+    }
+    s.nextToUpdate = kHcBase + (uint32_t)size;
+}
+
 // Levels 3..9: LZ4HC_compress_hashChain (lz4hc.c:1121-1363), nbSearches = 1 << (level - 1) (table :92-106),
 // patternAnalysis only above 128 attempts (level 9).  The goto structure of the reference is kept: it IS the algorithm.
-DEV int hc_compress_chain(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w)
+DEV int hc_compress_chain(const uint8_t* src, const int pfx, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w, const HcDict& d)
 {
     if ((uint32_t)n > (uint32_t)kMaxInput) return 0;                                             // :1388
     const bool limited = cap < compress_bound(n);
     const int  maxNb = 1 << (level - 1);
     const bool pa = maxNb > 128;
-    hc_reset_tables(w);
-    HcState s; s.src = src; s.n = n; s.w = w; s.nextToUpdate = kHcBase;
+    HcState s; s.src = src; s.pfx = pfx; s.w = w; s.d = d;
+    hc_prime(s, level);
 
-    int ip = 0, anchor = 0, op = 0;
+    const int N = pfx + n;                                                                       // positions count from the segment
+    int ip = pfx, anchor = pfx, op = 0;
     const int oend = cap;
-    const int mflimit = n - kMfLimit;
-    const int matchlimit = n - kLastLiterals;
+    const int mflimit = N - kMfLimit;
+    const int matchlimit = N - kLastLiterals;
     const int kOptimalMl = 15 - 1 + kMinMatch;                                                   // OPTIMAL_ML, lz4hc.c:75
     int start0 = 0, start2 = 0, start3 = 0;
     HcMatch m0 = {0, 0, 0}, m1 = {0, 0, 0}, m2 = {0, 0, 0}, m3 = {0, 0, 0};
@@ -361,60 +456,93 @@ search3:
         goto search3;
     }
 last_literals:
-    return hc_last_literals(src, n, anchor, dst, op, limited, oend);
+    return hc_last_literals(src, N, anchor, dst, op, limited, oend);
 }
 
-// Level 2: LZ4MID_compress (lz4hc.c:521-775).  Two 16 K-entry tables inside the HC hash table: 4-byte hashes in the lower
-// half, 7-of-8-byte hashes in the upper half (:141-151, :532-533).
-DEV uint32_t mid_hash4(const uint8_t* p) { return (ld32u(p) * 2654435761u) >> (32 - 14); }
-DEV uint32_t mid_hash8(const uint8_t* p) { return (uint32_t)(((ld64u(p) << 8) * 58295818150454627ull) >> (64 - 14)); }
+// Level 2: LZ4MID_compress (lz4hc.c:521-775).
 
-DEV int hc_compress_mid(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap, HcWork w)
+// One candidate of a level-2 table: length of the match at `ip` against index `pos` (0: none).  A candidate inside the
+// segment is counted up to the segment's end only (safeLen, lz4hc.c:587-596, :637-646); `prefixOnly` is the ip+1 look (:616).
+DEV int mid_try(const uint8_t* src, int ip, uint32_t ipIndex, uint32_t pos, uint32_t prefixIdx, const uint8_t* mlim, bool prefixOnly)
+{
+    if (ipIndex - pos > 65535u) return 0;
+    if (pos >= prefixIdx) return hc_count(src + ip, src + (pos - kHcBase), mlim);
+    if (prefixOnly || pos < kHcBase) return 0;
+    const uint8_t* lim = src + ip + (prefixIdx - pos);
+    if (lim > mlim) lim = mlim;
+    return hc_count(src + ip, src + (pos - kHcBase), lim);
+}
+
+// LZ4MID_searchExtDict (lz4hc.c:420-470): the level-2 tables of a dictionary context, long hash first.  gDictEnd = kHcBase.
+DEV HcMatch mid_search_ctx(const HcDict& d, const uint8_t* ipp, uint32_t ipIndex, const uint8_t* mlim)
+{
+    const uint32_t lEnd = kHcBase + (uint32_t)d.len;
+    HcMatch m; m.len = 0; m.off = 0; m.back = 0;
+    for (int k = 0; k < 2; ++k) {
+        const uint32_t l = k == 0 ? d.hash[16384 + mid_hash8(ipp)] : d.hash[mid_hash4(ipp)];
+        const uint32_t mIdx = l + kHcBase - lEnd;
+        if (ipIndex - mIdx <= 65535u) {
+            const uint8_t* const mp = d.bytes + (l - kHcBase);
+            size_t safe = (size_t)(lEnd - l);
+            if ((size_t)(mlim - ipp) < safe) safe = (size_t)(mlim - ipp);
+            const int mlt = hc_count(ipp, mp, ipp + safe);
+            if (mlt >= kMinMatch) { m.len = mlt; m.off = (int)(ipIndex - mIdx); return m; }
+        }
+    }
+    return m;
+}
+
+DEV int hc_compress_mid(const uint8_t* src, const int pfx, const int n, uint8_t* __restrict__ dst, const int cap, HcWork w, const HcDict& d)
 {
     if ((uint32_t)n > (uint32_t)kMaxInput) return 0;
     const bool limited = cap < compress_bound(n);
-    hc_reset_tables(w);
+    HcState s; s.src = src; s.pfx = pfx; s.w = w; s.d = d;
+    hc_prime(s, 2);
     uint32_t* const h4t = w.hash;
     uint32_t* const h8t = w.hash + 16384;
-    int ip = 0, anchor = 0, op = 0;
+    const int N = pfx + n;
+    int ip = pfx, anchor = pfx, op = 0;
     const int oend = cap;
-    const int mflimit = n - kMfLimit;
-    const int matchlimit = n - kLastLiterals;
-    const uint32_t ilimitIdx = (uint32_t)(n - 8) + kHcBase;
+    const int mflimit = N - kMfLimit;
+    const int matchlimit = N - kLastLiterals;
+    const uint32_t prefixIdx = kHcBase + (uint32_t)pfx;
+    const uint32_t ilimitIdx = (uint32_t)(N - 8) + kHcBase;
     const uint8_t* const mlim = src + matchlimit;
 
     if (n >= kMinLength) while (ip <= mflimit) {
         const uint32_t ipIndex = (uint32_t)ip + kHcBase;
         int ml = 0; uint32_t dist = 0;
-        {   // long match (:572-601); candidates below the prefix start do not exist for an independent block
+        {   // long match (:572-601)
             const uint32_t h8 = mid_hash8(src + ip);
             const uint32_t pos8 = h8t[h8];
             h8t[h8] = ipIndex;
-            if (ipIndex - pos8 <= 65535u && pos8 >= kHcBase) {
-                ml = hc_count(src + ip, src + (pos8 - kHcBase), mlim);
-                if (ml >= kMinMatch) dist = ipIndex - pos8; else ml = 0;
-            }
+            ml = mid_try(src, ip, ipIndex, pos8, prefixIdx, mlim, false);
+            if (ml >= kMinMatch) dist = ipIndex - pos8; else ml = 0;
         }
-        if (!ml) {   // short match, then one look at ip+1 for a longer one (:603-650)
+        if (!ml) {   // short match, then one look at ip+1 for a longer one inside the prefix (:603-650)
             const uint32_t h4 = mid_hash4(src + ip);
             const uint32_t pos4 = h4t[h4];
             h4t[h4] = ipIndex;
-            if (ipIndex - pos4 <= 65535u && pos4 >= kHcBase) {
-                ml = hc_count(src + ip, src + (pos4 - kHcBase), mlim);
-                if (ml >= kMinMatch) {
+            ml = mid_try(src, ip, ipIndex, pos4, prefixIdx, mlim, false);
+            if (ml >= kMinMatch) {
+                dist = ipIndex - pos4;
+                if (pos4 >= prefixIdx) {
                     const uint32_t h8 = mid_hash8(src + ip + 1);
                     const uint32_t pos8 = h8t[h8];
                     const uint32_t m2d = ipIndex + 1 - pos8;
-                    dist = ipIndex - pos4;
-                    if (m2d <= 65535u && pos8 >= kHcBase && ip < mflimit) {
+                    if (m2d <= 65535u && pos8 >= prefixIdx && ip < mflimit) {
                         const int ml2 = hc_count(src + ip + 1, src + (pos8 - kHcBase), mlim);
                         if (ml2 > ml) { h8t[h8] = ipIndex + 1; ip++; ml = ml2; dist = m2d; }
                     }
-                } else ml = 0;
-            }
+                }
+            } else ml = 0;
+        }
+        if (!ml && d.mode == kHcCtx && ipIndex - kHcBase < 65535u - 8u) {                        // :652-665
+            const HcMatch dm = mid_search_ctx(d, src + ip, ipIndex, mlim);
+            if (dm.len >= kMinMatch) { ml = dm.len; dist = (uint32_t)dm.off; }
         }
         if (!ml) { ip += 1 + ((ip - anchor) >> 9); continue; }                                   // :668
-        while (ip > anchor && (uint32_t)ip > dist && src[ip - 1] == src[ip - (int)dist - 1]) { ip--; ml++; }   // :673-675
+        while (ip > anchor && (uint32_t)(ip - pfx) > dist && src[ip - 1] == src[ip - (int)dist - 1]) { ip--; ml++; }   // :673-675
         // "fill table with beginning of match": the index stays the loop-top ipIndex although ip may have moved (:678-680)
         h8t[mid_hash8(src + ip + 1)] = ipIndex + 1;
         h8t[mid_hash8(src + ip + 2)] = ipIndex + 2;
@@ -422,7 +550,7 @@ DEV int hc_compress_mid(const uint8_t* __restrict__ src, const int n, uint8_t* _
         if (hc_encode_seq(src, &ip, dst, &op, &anchor, ml, (int)dist, limited, oend)) return 0;
         {   const uint32_t endIdx = (uint32_t)ip + kHcBase;                                      // :695-706
             if (endIdx - 2 < ilimitIdx) {
-                if (ip > 5) h8t[mid_hash8(src + ip - 5)] = endIdx - 5;
+                if (ip - pfx > 5) h8t[mid_hash8(src + ip - 5)] = endIdx - 5;
                 h8t[mid_hash8(src + ip - 3)] = endIdx - 3;
                 h8t[mid_hash8(src + ip - 2)] = endIdx - 2;
                 h4t[mid_hash4(src + ip - 2)] = endIdx - 2;
@@ -430,11 +558,11 @@ DEV int hc_compress_mid(const uint8_t* __restrict__ src, const int n, uint8_t* _
             }
         }
     }
-    return hc_last_literals(src, n, anchor, dst, op, limited, oend);
+    return hc_last_literals(src, N, anchor, dst, op, limited, oend);
 }
 
 // Level table rows 10..12 (lz4hc.c:92-106): {nbSearches, targetLength}; fullUpdate only at level 12 (:1406).
-DEV int hc_compress_opt(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w)
+DEV int hc_compress_opt(const uint8_t* src, const int pfx, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w, const HcDict& d)
 {
     if ((uint32_t)n > (uint32_t)kMaxInput) return 0;                                             // :1388
     const bool limited = cap < compress_bound(n);                                                // :1505-1508
@@ -444,13 +572,14 @@ DEV int hc_compress_opt(const uint8_t* __restrict__ src, const int n, uint8_t* _
     if (sufficient >= (size_t)kHcOptNum) sufficient = kHcOptNum - 1;                             // :1860
     HcOpt* const opt = w.opt;
 
-    hc_reset_tables(w);
-    HcState s; s.src = src; s.n = n; s.w = w; s.nextToUpdate = kHcBase;
+    HcState s; s.src = src; s.pfx = pfx; s.w = w; s.d = d;
+    hc_prime(s, level);
 
-    int ip = 0, anchor = 0, op = 0;
+    const int N = pfx + n;
+    int ip = pfx, anchor = pfx, op = 0;
     const int oend = cap;
-    const int mflimit = n - kMfLimit;
-    const int matchlimit = n - kLastLiterals;
+    const int mflimit = N - kMfLimit;
+    const int matchlimit = N - kLastLiterals;
 
     while (ip <= mflimit) {                                                                      // :1863
         const int llen = ip - anchor;
@@ -534,18 +663,33 @@ DEV int hc_compress_opt(const uint8_t* __restrict__ src, const int n, uint8_t* _
             }
         }
     }
-    return hc_last_literals(src, n, anchor, dst, op, limited, oend);                             // :2067-2098
+    return hc_last_literals(src, N, anchor, dst, op, limited, oend);                             // :2067-2098
 }
 
-// LZ4_compress_HC(level) for every level plz4 routes to the HC entry point (2..12); LZ4HC_getCLevelParams, lz4hc.c:108-117
-DEV int hc_compress(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap, int level, HcWork w)
+// LZ4_compress_HC(level) / LZ4_compress_HC_continue for every level plz4 routes to the HC entry points (2..12);
+// LZ4HC_getCLevelParams, lz4hc.c:108-117.  kHcExt: the d.len bytes before `blk` are the external segment.
+DEV int hc_compress(const uint8_t* blk, const int n, uint8_t* __restrict__ dst, const int cap, int level, HcWork w, const HcDict& d)
 {
     if (level < 1) level = 9;
     if (level > 12) level = 12;
-    if (level <= 2) return hc_compress_mid(src, n, dst, cap, w);
-    if (level <= 9) return hc_compress_chain(src, n, dst, cap, level, w);
-    return hc_compress_opt(src, n, dst, cap, level, w);
+    const int pfx = d.mode == kHcExt ? d.len : 0;
+    const uint8_t* const src = blk - pfx;
+    if (level <= 2) return hc_compress_mid(src, pfx, n, dst, cap, w, d);
+    if (level <= 9) return hc_compress_chain(src, pfx, n, dst, cap, level, w, d);
+    return hc_compress_opt(src, pfx, n, dst, cap, level, w, d);
+}
+DEV int hc_compress(const uint8_t* blk, const int n, uint8_t* __restrict__ dst, const int cap, int level, HcWork w)
+{
+    HcDict d; d.mode = kHcNone; d.len = 0; d.bytes = nullptr; d.hash = nullptr; d.chain = nullptr;
+    return hc_compress(blk, n, dst, cap, level, w, d);
 }
 
+// The tables a dictionary context carries (clz4.NewDictCtxHC, clz4.go:122-147 == LZ4_loadDictHC): `w` <- tables over dict[0, len).
+DEV void hc_prime_dict(const uint8_t* dict, int len, int level, HcWork w)
+{
+    HcState s; s.src = dict; s.pfx = len; s.w = w;
+    s.d.mode = kHcNone; s.d.len = 0; s.d.bytes = nullptr; s.d.hash = nullptr; s.d.chain = nullptr;
+    hc_prime(s, level);
+}
 
 }  // namespace plz4

@@ -45,6 +45,9 @@ struct CodecArgs {
     // HC levels 2..12
     int             level;
     uint8_t*        hcWork;                         // gridDim.x x kHcWorkBytes
+    const uint32_t* hcDictHash;                     // HC + dictionary: the dictionary context's tables for this level's strategy
+    const uint16_t* hcDictChain;                    //   (clz4.NewDictCtxHC, clz4.go:122-147), built by k_hc_dict_prime
+    int             hcEx;                           // HC call with a dictionary and/or linked blocks: inputs have 64 KiB of scratch in front
 };
 
 __device__ __forceinline__ int next_block(uint32_t* q)
@@ -237,23 +240,54 @@ __device__ __forceinline__ HcWork hc_work_of(const CodecArgs& a)
     w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2);
     return w;
 }
+// How block i of an HC call is primed: clz4.StreamCtxHC (clz4.go:181-209, dictionary + independent blocks),
+// clz4.StreamLinkedCtxHC (:250-283) + async/writer.go:412-437 (_genDict: the previous block's last <= 64 KiB).  In the
+// dictionary / linked modes every input block has 64 KiB of scratch in front of it (host_codec lays the staging out that
+// way): an external segment is copied there so that it lies right before the block, which is what hc_compress(kHcExt) reads.
+__device__ __forceinline__ HcDict hc_dict_of(const CodecArgs& a, int i, int n, const uint8_t* s, bool rawApi)
+{
+    HcDict d; d.mode = kHcNone; d.len = 0; d.bytes = nullptr; d.hash = nullptr; d.chain = nullptr;
+    const uint8_t* seg = nullptr; int segLen = -1;
+    if (!rawApi && a.linked) {
+        if (i > 0) { const int pl = block_len(a, i - 1); segLen = pl < 65536 ? pl : 65536; seg = a.src + (int64_t)(i - 1) * a.srcStride + (pl - segLen); }
+        else if (a.prevTailLen >= 0) { seg = a.prevTail; segLen = a.prevTailLen; }
+    }
+    if (segLen < 0 && (a.dict != nullptr || a.dictLen >= 0)) {           // a dictionary context is attached (lz4hc.c:1438-1461)
+        const int dl = a.dictLen > 0 ? a.dictLen : 0;
+        if (n > 4096) { seg = a.dict; segLen = dl; }                      // its state is copied: same as LZ4_loadDictHC + setExternalDict
+        else { d.mode = kHcCtx; d.len = dl; d.bytes = a.dict; d.hash = a.hcDictHash; d.chain = a.hcDictChain; }
+    }
+    if (segLen >= 0) {
+        d.mode = kHcExt; d.len = segLen;
+        if (segLen > 0) { wave_copy(const_cast<uint8_t*>(s) - segLen, seg, segLen); WAVE_FENCE(); }
+    }
+    return d;
+}
 __global__ __launch_bounds__(64) void k_encode_raw_hc(CodecArgs a)
 {
     const HcWork w = hc_work_of(a);
+    const bool dictMode = a.hcEx != 0;
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
         const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
-        const int r = hc_compress(a.src + (int64_t)i * a.srcStride, block_len(a, i), a.dst + (int64_t)i * a.dstStride, cap, a.level, w);
+        const int n = block_len(a, i);
+        const uint8_t* s = a.src + (int64_t)i * a.srcStride;
+        int r;
+        if (dictMode) r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, w, hc_dict_of(a, i, n, s, true));
+        else          r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, w);
         if ((threadIdx.x & 63u) == 0) a.result[i] = r;
     }
 }
 __global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
 {
     const HcWork w = hc_work_of(a);
+    const bool exMode = a.hcEx != 0;
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
         const int      n   = block_len(a, i);
         const uint8_t* s   = a.src + (int64_t)i * a.srcStride;
         uint8_t*       rec = a.dst + (int64_t)i * a.dstStride;
-        int      c    = hc_compress(s, n, rec + 4, a.bsz, a.level, w);   // capacity == bsz (blk.go:73); indie.go:80-88
+        int c;                                                           // capacity == bsz (blk.go:73); indie.go:80-88
+        if (exMode) c = hc_compress(s, n, rec + 4, a.bsz, a.level, w, hc_dict_of(a, i, n, s, false));
+        else        c = hc_compress(s, n, rec + 4, a.bsz, a.level, w);
         uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
         WAVE_FENCE();
         if (c == 0) { wave_copy(rec + 4, s, n); c = n; word = 0x80000000u | ((uint32_t)n & 0x7FFFFFFFu); }
@@ -266,6 +300,15 @@ __global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
         }
         if ((threadIdx.x & 63u) == 0) { st32u(rec, word); a.result[i] = len; }
     }
+}
+// clz4.NewDictCtxHC (clz4.go:122-147): workgroup 0 builds the level-2 (lz4mid) tables of a dictionary, workgroup 1 the
+// hash-chain tables every other level shares.  tabs = 2 x kHcWorkBytes.
+__global__ __launch_bounds__(64) void k_hc_dict_prime(const uint8_t* dict, int len, uint8_t* tabs)
+{
+    uint8_t* ws = tabs + (size_t)blockIdx.x * kHcWorkBytes;
+    HcWork w; w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + kHcHashEntries * 4);
+    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2);
+    hc_prime_dict(dict, len, blockIdx.x == 0 ? 2 : 3, w);
 }
 
 __global__ __launch_bounds__(64) void k_decode_raw(CodecArgs a)
@@ -392,6 +435,7 @@ struct plz4hip_ctx {
 struct plz4hip_dict {
     uint8_t*  d_bytes = nullptr;  int len = 0;      // len < 8: the dictionary is dropped by liblz4 (lz4.c:1613-1615)
     uint32_t* d_table = nullptr;
+    uint8_t*  d_hc = nullptr;                       // clz4.DictCtxHC: [level-2 tables][hash-chain tables], kHcWorkBytes each
     std::vector<uint8_t> h_bytes;
 };
 
@@ -699,16 +743,18 @@ namespace {
 // Layout of one chunk in a slot (same offsets in the pinned host buffer and in the device buffer):
 //   [srcLen n][dstCap n][result n][status n][outLen n][outOff n+1 (int64)] | inputs at inStride | outputs at outStride
 // and, device only, the outputs once more back to back (compacted) -- that is what travels back over PCIe.
-struct Staging { size_t offA, offB, offRes, offSt, offLen, offOff, offIn, offOut, offPack, total; int64_t inStride, outStride; };
+struct Staging { size_t offA, offB, offRes, offSt, offLen, offOff, offIn, offOut, offPack, total; int64_t inStride, outStride; size_t gap; };
 
-Staging plan(int n, int maxIn, int maxOut)
+// gap: bytes of scratch in front of every input block (HC with a dictionary / linked blocks: the external segment goes there)
+Staging plan(int n, int maxIn, int maxOut, size_t gap = 0)
 {
     Staging s{};
+    s.gap = gap;
     const size_t arr = round_up((size_t)n * 4, 256);
     s.offA = 0; s.offB = arr; s.offRes = 2 * arr; s.offSt = 3 * arr; s.offLen = 4 * arr;
     s.offOff = 5 * arr;
     s.offIn = s.offOff + round_up((size_t)(n + 1) * 8, 256);
-    s.inStride = (int64_t)round_up((size_t)maxIn + 16, 16);
+    s.inStride = (int64_t)round_up((size_t)maxIn + gap + 16, 16);
     s.outStride = (int64_t)round_up((size_t)maxOut + 16, 16);
     s.offOut = s.offIn + (size_t)n * s.inStride;
     s.offPack = s.offOut + (size_t)n * s.outStride;
@@ -753,16 +799,17 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
 
     size_t kChunkBytes = (size_t)6 << 30;      // x kSlots in flight: enough blocks for every encoder wave slot at 4 MiB blocks
     if (const char* v = getenv("PLZ4HIP_HOST_CHUNK_MB")) { const long mb = atol(v); if (mb > 0) kChunkBytes = (size_t)mb << 20; }   // tests: force many chunks
+    const size_t gap = (hcMode && dictMode) ? 65536 : 0;
     int cb = nBlocks;
     {
-        const Staging one = plan(1, maxIn, maxOut);
+        const Staging one = plan(1, maxIn, maxOut, gap);
         const size_t per = (size_t)one.inStride + 2 * (size_t)one.outStride;
         if (!chained && per * (size_t)nBlocks > kChunkBytes) { cb = (int)(kChunkBytes / per); if (cb < 1) cb = 1; }
     }
     const int nChunks = (nBlocks + cb - 1) / cb;
     // HC kernels index one shared workspace by workgroup: never two of them at once
     const int nSlots = hcMode ? 1 : (nChunks < plz4hip_ctx::kSlots ? nChunks : plz4hip_ctx::kSlots);
-    const Staging st = plan(cb, maxIn, maxOut);
+    const Staging st = plan(cb, maxIn, maxOut, gap);
     const size_t offExtra = st.total;                          // [prevTail 64 KiB][window 2 x 64 KiB][windowLen]
     const size_t slotBytes = st.total + (dictMode ? 3 * 65536 + 256 : 0);
     for (int i = 0; i < nSlots; ++i) if (int rc = ensure_slot(c, i, slotBytes, slotBytes)) return rc;
@@ -776,13 +823,13 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         size_t inBytes = 0;
         for (int i = 0; i < nb; ++i) { hA[i] = srcLen[b0 + i]; hB[i] = (mode == 0 || mode == 1) ? dstCap[b0 + i] : 0; inBytes += (size_t)srcLen[b0 + i]; }
         parallel_blocks(nb, inBytes, [&](int i) {
-            if (srcLen[b0 + i]) memcpy(sl.h + st.offIn + (size_t)i * st.inStride, src[b0 + i], (size_t)srcLen[b0 + i]);
+            if (srcLen[b0 + i]) memcpy(sl.h + st.offIn + st.gap + (size_t)i * st.inStride, src[b0 + i], (size_t)srcLen[b0 + i]);
         });
         HIPCHK(c, hipMemcpyAsync(sl.d, sl.h, st.offRes, hipMemcpyHostToDevice, s));                                   // srcLen, dstCap
         HIPCHK(c, hipMemcpyAsync(sl.d + st.offIn, sl.h + st.offIn, (size_t)nb * st.inStride, hipMemcpyHostToDevice, s));
         hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
         CodecArgs a{};
-        a.src = sl.d + st.offIn; a.srcStride = st.inStride; a.srcLen = (const int32_t*)(sl.d + st.offA);
+        a.src = sl.d + st.offIn + st.gap; a.srcStride = st.inStride; a.srcLen = (const int32_t*)(sl.d + st.offA);
         a.dst = sl.d + st.offOut; a.dstStride = st.outStride; a.dstCap = (const int32_t*)(sl.d + st.offB);
         a.result = (int32_t*)(sl.d + st.offRes); a.status = (int32_t*)(sl.d + st.offSt);
         a.queue = q; a.nBlocks = nb; a.bsz = bsz; a.blockChecksum = blockChecksum; a.dstCapAll = bsz + 8;
@@ -790,6 +837,13 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         if (hcMode) { a.level = dj->level; a.hcWork = c->d_hc; }
         if (dictMode) {
             if (dj->dict) { a.dict = dj->dict->d_bytes; a.dictLen = dj->dict->len; a.dictTable = dj->dict->d_table; }
+            if (hcMode) {
+                a.hcEx = 1;
+                if (dj->dict) {
+                    const uint8_t* t = dj->dict->d_hc + (dj->level <= 2 ? 0 : (size_t)kHcWorkBytes);
+                    a.hcDictHash = (const uint32_t*)t; a.hcDictChain = (const uint16_t*)(t + kHcHashEntries * 4);
+                }
+            }
             a.linked = dj->linked;
             if (dj->prevTail && dj->prevTailLen >= 0) {
                 memcpy(sl.h + offExtra, dj->prevTail, (size_t)dj->prevTailLen);
@@ -928,7 +982,13 @@ int plz4hip_dict_create(plz4hip_ctx* c, const void* dict, int dictLen, plz4hip_d
     if (e == hipSuccess) e = hipMalloc((void**)&d->d_table, 4096 * sizeof(uint32_t));
     if (e == hipSuccess && dictLen) e = hipMemcpy(d->d_bytes, d->h_bytes.data(), (size_t)dictLen, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d->d_table, tab.data(), 4096 * sizeof(uint32_t), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { if (d->d_bytes) hipFree(d->d_bytes); if (d->d_table) hipFree(d->d_table); delete d; return fail(c, PLZ4HIP_E_DEVICE, "plz4hip_dict_create", e); }
+    if (e == hipSuccess) e = hipMalloc((void**)&d->d_hc, 2 * (size_t)kHcWorkBytes);
+    if (e == hipSuccess) {                                                       // clz4.NewDictCtxHC for both table strategies
+        hipLaunchKernelGGL(k_hc_dict_prime, dim3(2), dim3(64), 0, c->stream, (const uint8_t*)d->d_bytes, dictLen, d->d_hc);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    if (e != hipSuccess) { if (d->d_bytes) hipFree(d->d_bytes); if (d->d_table) hipFree(d->d_table); if (d->d_hc) hipFree(d->d_hc); delete d; return fail(c, PLZ4HIP_E_DEVICE, "plz4hip_dict_create", e); }
     *out = d;
     return PLZ4HIP_OK;
 }
@@ -939,6 +999,7 @@ void plz4hip_dict_destroy(plz4hip_ctx* c, plz4hip_dict* d)
     if (c) hipSetDevice(c->device);
     if (d->d_bytes) hipFree(d->d_bytes);
     if (d->d_table) hipFree(d->d_table);
+    if (d->d_hc) hipFree(d->d_hc);
     delete d;
 }
 
@@ -946,8 +1007,8 @@ int plz4hip_compress_batch_dict(plz4hip_ctx* c, int nBlocks, const void* const* 
                                 void* const* dst, const int32_t* dstCap, int level, const plz4hip_dict* dict, int32_t* result)
 {
     if (!c || !dict || nBlocks < 0 || (nBlocks && (!src || !srcLen || !dst || !dstCap || !result))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_compress_batch_dict: bad argument");
-    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
-    DictJob j; j.dict = dict; j.any = true;
+    if (level != 1 && !is_hc_level(level)) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1..12 are built");
+    DictJob j; j.dict = dict; j.any = true; j.level = level;
     return host_codec(c, 0, nBlocks, src, srcLen, dst, dstCap, 0, 0, result, nullptr, &j);
 }
 
@@ -964,10 +1025,13 @@ int plz4hip_encode_records_ex(plz4hip_ctx* c, int nBlocks, const void* const* sr
                               const void* prevTail, int prevTailLen, void* const* rec, int32_t* recLen)
 {
     if (!c || nBlocks < 0 || bsz <= 0 || (nBlocks && (!src || !srcLen || !rec || !recLen))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_encode_records_ex: bad argument");
-    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    if (level != 1 && !is_hc_level(level)) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1..12 are built");
     for (int i = 0; i < nBlocks; ++i) if (srcLen[i] > bsz) return fail(c, PLZ4HIP_E_ARG, "source block larger than block size");
-    if (!linked && !dict) return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr);
-    DictJob j; j.dict = dict; j.linked = linked; j.prevTail = prevTail; j.prevTailLen = (linked && prevTail) ? prevTailLen : -1; j.any = true;
+    if (!linked && !dict) {
+        if (is_hc_level(level)) { DictJob j; j.level = level; return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr, &j); }
+        return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr);
+    }
+    DictJob j; j.dict = dict; j.linked = linked; j.prevTail = prevTail; j.prevTailLen = (linked && prevTail) ? prevTailLen : -1; j.any = true; j.level = level;
     return host_codec(c, 2, nBlocks, src, srcLen, rec, nullptr, bsz, blockChecksum, recLen, nullptr, &j);
 }
 

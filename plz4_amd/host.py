@@ -4,6 +4,7 @@ plug another one in through the same vtable the C++ layer exposes (`vtable_engin
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -115,9 +116,12 @@ class Engine:
         if not handle:
             raise RuntimeError("plz4h: no block engine (is an MI355X visible / the library built?)")
         self.h = handle
+        self._children = weakref.WeakSet()      # writers / readers still alive: they hold engine resources (dictionary contexts)
 
     def close(self):
         if self.h:
+            for c in list(self._children):      # free them first: their destructors call back into the engine
+                c._free()
             lib().plz4h_engine_free(self.h); self.h = None
 
 
@@ -139,6 +143,7 @@ class Writer:
     def __init__(self, engine: Engine, **kw):
         self.L = lib(); self.o = make_opts(**kw)
         self.h = self.L.plz4h_writer_new(engine.h, C.byref(self.o))
+        engine._children.add(self)
 
     def write(self, data):
         a, p = _buf(data); n = C.c_size_t(0)
@@ -164,9 +169,13 @@ class Writer:
         p = C.c_void_p(); n = self.L.plz4h_writer_progress(self.h, C.byref(p))
         return _pairs(p, n)
 
+    def _free(self):
+        if self.h:
+            self.L.plz4h_writer_free(self.h); self.h = None
+
     def __del__(self):
         try:
-            if self.h: self.L.plz4h_writer_free(self.h); self.h = None
+            self._free()
         except Exception:
             pass
 
@@ -178,6 +187,7 @@ class Reader:
         self.L = lib(); self.o = make_opts(**kw)
         a, p = _buf(data)
         self.h = self.L.plz4h_reader_new(engine.h, C.byref(self.o), p, a.size)
+        engine._children.add(self)
 
     def read(self, n):
         buf = np.empty(max(n, 1), dtype=np.uint8); got = C.c_size_t(0)
@@ -197,9 +207,13 @@ class Reader:
     def close(self):
         return Err(self.L.plz4h_reader_close(self.h))
 
+    def _free(self):
+        if self.h:
+            self.L.plz4h_reader_free(self.h); self.h = None
+
     def __del__(self):
         try:
-            if self.h: self.L.plz4h_reader_free(self.h); self.h = None
+            self._free()
         except Exception:
             pass
 

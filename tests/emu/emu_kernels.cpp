@@ -44,6 +44,39 @@ int emu_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level)
     return plz4::hc_compress(src, n, dst, cap, level, w);
 }
 
+static plz4::HcWork emu_hc_work(uint8_t* ws)
+{
+    plz4::HcWork w;
+    w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + plz4::kHcHashEntries * 4);
+    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2);
+    return w;
+}
+
+// HC with an external segment (mode 1: seg[0..segLen) is laid out right before a copy of the block, as the kernels do) or
+// under a dictionary context (mode 2: tables built by hc_prime_dict, block <= 4 KiB).
+int emu_compress_hc_dict(const uint8_t* src, int n, uint8_t* dst, int cap, int level, const uint8_t* seg, int segLen, int mode)
+{
+    static thread_local uint8_t* ws = nullptr; static thread_local uint8_t* dws = nullptr;
+    if (!ws) { ws = (uint8_t*)malloc(plz4::kHcWorkBytes); dws = (uint8_t*)malloc(plz4::kHcWorkBytes); }
+    plz4::HcDict d; d.mode = mode; d.len = segLen; d.bytes = nullptr; d.hash = nullptr; d.chain = nullptr;
+    if (mode == plz4::kHcExt) {
+        uint8_t* cat = (uint8_t*)malloc((size_t)segLen + (size_t)n + 64);
+        if (segLen) memcpy(cat, seg, (size_t)segLen);
+        if (n) memcpy(cat + segLen, src, (size_t)n);
+        const int r = plz4::hc_compress(cat + segLen, n, dst, cap, level, emu_hc_work(ws), d);
+        free(cat);
+        return r;
+    }
+    uint8_t* dcopy = (uint8_t*)malloc((size_t)segLen + 64);
+    if (segLen) memcpy(dcopy, seg, (size_t)segLen);
+    const plz4::HcWork dw = emu_hc_work(dws);
+    plz4::hc_prime_dict(dcopy, segLen, level, dw);
+    d.bytes = dcopy; d.hash = dw.hash; d.chain = dw.chain;
+    const int r = plz4::hc_compress(src, n, dst, cap, level, emu_hc_work(ws), d);
+    free(dcopy);
+    return r;
+}
+
 int emu_encode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, const uint8_t* dict, int dictSize, int mode,
                           const uint32_t* dictTable)
 {

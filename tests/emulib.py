@@ -59,6 +59,17 @@ class Emu:
         r = int(self.L.emu_compress_hc(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, level))
         return r, dst[:max(r, 0)]
 
+    def compress_hc_dict(self, src, cap, level, seg, mode):
+        """mode 1: `seg` is the external segment in front of the block (linked tail / dictionary, block > 4 KiB);
+        mode 2: `seg` is the dictionary of an attached context (block <= 4 KiB)."""
+        self.L.emu_compress_hc_dict.restype = C.c_int
+        self.L.emu_compress_hc_dict.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+        dst = np.empty(max(cap, 1) + 32, dtype=np.uint8)
+        nul = C.cast(None, u8p)
+        r = int(self.L.emu_compress_hc_dict(_ptr(src) if src.size else nul, src.size, _ptr(dst), cap, level,
+                                            _ptr(seg) if seg.size else nul, seg.size, mode))
+        return r, dst[:max(r, 0)]
+
     def set_descending(self, d: bool):
         self.L.emu_set_descending(int(d))
 

@@ -4,12 +4,17 @@
  * never part of plz4_amd/libplz4hip.so. */
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../oracle/plz4_oracle.h"
+
+/* ORACLE_ENGINE_ANY_LEVEL=1: answer every level with the level-1 encoder, so that the host layer's handling of levels > 1
+ * (e.g. linked HC frames have no stored-block fallback) can be exercised without a GPU.  Test switch only. */
+static int any_level(void) { const char* v = getenv("ORACLE_ENGINE_ANY_LEVEL"); return v && v[0] == '1'; }
 
 static int o_compress(void* u, int n, const void* const* src, const int32_t* sl, void* const* dst, const int32_t* dc, int level, int32_t* res)
 {
     (void)u;
-    if (level != 1) return -4;
+    if (level != 1 && !any_level()) return -4;
     for (int i = 0; i < n; i++) res[i] = orc_compress_fast((const uint8_t*)src[i], sl[i], (uint8_t*)dst[i], dc[i]);
     return 0;
 }
@@ -22,7 +27,7 @@ static int o_decompress(void* u, int n, const void* const* src, const int32_t* s
 static int o_encode_records(void* u, int n, const void* const* src, const int32_t* sl, int bsz, int level, int bc, void* const* rec, int32_t* rl)
 {
     (void)u;
-    if (level != 1) return -4;
+    if (level != 1 && !any_level()) return -4;
     for (int i = 0; i < n; i++) rl[i] = orc_block_record((const uint8_t*)src[i], sl[i], bsz, bc, (uint8_t*)rec[i]);
     return 0;
 }
@@ -65,7 +70,7 @@ static int indie_dict(const odict* d, const uint8_t* src, int n, uint8_t* dst, i
 }
 static int o_compress_dict(void* u, int n, const void* const* src, const int32_t* sl, void* const* dst, const int32_t* dc, int level, void* d, int32_t* res)
 {
-    (void)u; if (level != 1) return -4;
+    (void)u; if (level != 1 && !any_level()) return -4;
     for (int i = 0; i < n; i++) res[i] = indie_dict((const odict*)d, (const uint8_t*)src[i], sl[i], (uint8_t*)dst[i], dc[i]);
     return 0;
 }
@@ -87,7 +92,7 @@ static int frame_record(int c, const uint8_t* src, int n, int bc, uint8_t* rec)
 static int o_encode_ex(void* u, int n, const void* const* src, const int32_t* sl, int bsz, int level, int bc, int linked, void* d,
                        const void* prevTail, int prevTailLen, void* const* rec, int32_t* rl)
 {
-    (void)u; if (level != 1) return -4;
+    (void)u; if (level != 1 && !any_level()) return -4;
     for (int i = 0; i < n; i++) {
         const uint8_t* s = (const uint8_t*)src[i];
         uint8_t* r = (uint8_t*)rec[i];

@@ -154,6 +154,10 @@ class Oracle:
         return r, out[:max(r, 0)]
 
 
+# an empty block still gets a valid address: with NULL the optimal parser of the reference (levels 10-12) dereferences it
+_ONE = np.zeros(16, dtype=np.uint8)
+
+
 class Ref:
     """The real thing: liblz4 v1.10.0 from /root/reference/internal/pkg/clz4 (oracle/Makefile `ref`)."""
 
@@ -184,9 +188,63 @@ class Ref:
         L.LZ4_compress_fast_continue.restype = C.c_int
         L.LZ4_compress_fast_continue.argtypes = [C.c_void_p, u8p, u8p, C.c_int, C.c_int, C.c_int]
 
+        L.LZ4_sizeofStateHC.restype = C.c_int
+        L.LZ4_initStreamHC.restype = C.c_void_p
+        L.LZ4_initStreamHC.argtypes = [C.c_void_p, C.c_size_t]
+        L.LZ4_resetStreamHC_fast.argtypes = [C.c_void_p, C.c_int]
+        L.LZ4_loadDictHC.restype = C.c_int
+        L.LZ4_loadDictHC.argtypes = [C.c_void_p, u8p, C.c_int]
+        L.LZ4_attach_HC_dictionary.argtypes = [C.c_void_p, C.c_void_p]
+        L.LZ4_compress_HC_continue.restype = C.c_int
+        L.LZ4_compress_HC_continue.argtypes = [C.c_void_p, u8p, u8p, C.c_int, C.c_int]
+
     @staticmethod
     def available():
         return os.path.exists(REF_SO)
+
+    # ---- the Go stream types of clz4.go over the real liblz4 (HC): a Go zero value is zeroed memory
+    def _zeroed_hc(self):
+        buf = C.create_string_buffer(self.L.LZ4_sizeofStateHC() + 64)
+        return buf, (C.addressof(buf) + 15) & ~15
+
+    def new_dict_ctx_hc(self, dct: np.ndarray, level: int):
+        """clz4.NewDictCtxHC (clz4.go:127-147).  Returns (keepalive, address)."""
+        data = np.ascontiguousarray(dct).copy()
+        buf, addr = self._zeroed_hc()
+        self.L.LZ4_resetStreamHC_fast(addr, level)
+        self.L.LZ4_loadDictHC(addr, _ptr(data) if data.size else C.cast(None, u8p), data.size)
+        return (buf, data), addr
+
+    def stream_ctx_hc(self, level: int, dict_addr):
+        """clz4.StreamCtxHC (clz4.go:181-209): returns compress(src, cap) on ONE reused stream, as a worker would."""
+        buf, addr = self._zeroed_hc()
+
+        def compress(src: np.ndarray, cap: int):
+            self.L.LZ4_resetStreamHC_fast(addr, level)
+            self.L.LZ4_attach_HC_dictionary(addr, dict_addr)
+            dst = np.empty(max(cap, 1), dtype=np.uint8)
+            r = int(self.L.LZ4_compress_HC_continue(addr, _ptr(src if src.size else _ONE), _ptr(dst), src.size, cap))
+            return r, dst[:max(r, 0)]
+        compress._keep = buf
+        return compress
+
+    def stream_linked_ctx_hc(self, level: int, dict_addr=None):
+        """clz4.StreamLinkedCtxHC (clz4.go:250-283): returns compress(src, cap, tail_or_None)."""
+        buf, addr = self._zeroed_hc()
+        self.L.LZ4_resetStreamHC_fast(addr, level)
+        if dict_addr is not None:
+            self.L.LZ4_attach_HC_dictionary(addr, dict_addr)
+
+        def compress(src: np.ndarray, cap: int, tail):
+            if tail is not None:
+                t = np.ascontiguousarray(tail)
+                self.L.LZ4_loadDictHC(addr, _ptr(t) if t.size else C.cast(None, u8p), t.size)
+                compress._tail = t
+            dst = np.empty(max(cap, 1), dtype=np.uint8)
+            r = int(self.L.LZ4_compress_HC_continue(addr, _ptr(src if src.size else _ONE), _ptr(dst), src.size, cap))
+            return r, dst[:max(r, 0)]
+        compress._keep = buf
+        return compress
 
     def new_stream(self):
         buf = C.create_string_buffer(self.L.LZ4_sizeofState() + 64)

@@ -174,12 +174,34 @@ def test_write_after_close(eng):
 
 
 def test_unsupported_modes_fail_loudly(eng):
-    """HC levels with linked blocks or a dictionary are not built yet: the writer reports ErrUnsupported, it never falls
-    back to other bytes."""
+    """An engine that answers PLZ4HIP_E_UNSUPPORTED (the oracle-backed test engine has no HC levels; the HIP engine builds every
+    level, tests/test_hc_dict.py): the writer reports ErrUnsupported, it never falls back to other bytes."""
     for kw in (dict(level=9, block_linked=True), dict(level=12, block_linked=True), dict(level=2, dictionary=b"abcd" * 64)):
         w = host.Writer(eng, parallel=1, **kw)
         w.write(b"some payload that needs compressing")
         assert int(w.close()) == host.ErrUnsupported
+
+
+def test_linked_frames_above_level_1_have_no_stored_fallback(eng, monkeypatch):
+    """compress/linked.go:47-49: linkedCompressorHC.Compress returns liblz4's error without joining zerr.ErrCompress, so
+    blk.CompressToBlk (blk/blk.go:75-86) does not store the block raw: the write fails.  Independent blocks at the same level,
+    and linked blocks at level 1, fall back to a stored block.  (The test engine answers level 9 with its level-1 encoder:
+    only the host layer's handling is under test here; the HIP engine's bytes are in tests/test_hc_dict.py.)"""
+    monkeypatch.setenv("ORACLE_ENGINE_ANY_LEVEL", "1")
+    noise = synth.random_bytes(3 * (64 << 10), seed=8).tobytes()
+    for par in (0, 2):
+        w = host.Writer(eng, parallel=par, level=9, block_size=host.BlockIdx64KB, block_linked=True)
+        w.write(noise)
+        assert int(w.close()) == host.ErrCompress
+        for kw in (dict(level=9, block_linked=False), dict(level=1, block_linked=True)):
+            w = host.Writer(eng, parallel=par, block_size=host.BlockIdx64KB, **kw)
+            w.write(noise)
+            assert not w.close()
+            n, out, err = host.Reader(eng, w.output()).write_to()
+            assert not err and out == noise
+    small = host.Writer(eng, parallel=2, level=9, block_size=host.BlockIdx64KB, block_linked=True)     # the _writeSync shortcut
+    small.write(noise[:65535])
+    assert int(small.close()) == host.ErrCompress
 
 
 # ------------------------------------------------------------------------------------------------ config 5 (wr_test.go: dict, linked, linked_with_dict)
