@@ -273,31 +273,67 @@ DEV uint64_t lane_range(int lo, int hi)          // bits lo..hi inclusive, 0 <= 
 // the table is initialised with position 0's entry, not with zero.  Larger blocks (raw block API) run untagged.
 DEV uint32_t seq_tag(uint32_t seq4) { return (seq4 * 2246822519u) >> 22; }
 
-template <bool U16>
+// kExt (the streaming flavours of lz4.c:930-1338 that plz4 reaches through LZ4_compress_fast_continue, see ExtEnc below): the
+// block has an external segment of `pfx` bytes lying IMMEDIATELY BEFORE it in memory, `src` points at the segment's first
+// byte, positions count from there, the block is [pfx, n).  Table entries then hold liblz4's own index, position + delta
+// (delta = 64 KiB - pfx once a dictionary was loaded), so that an empty slot -- index 0 -- is what it is for liblz4: the
+// segment's first byte when the segment is a full 64 KiB (noDictIssue), an invalid candidate otherwise (dictSmall,
+// lz4.c:1085-1087).  A candidate inside the segment needs no second code path: its bytes are at src + position like any
+// other, and a match that runs from the segment into the block is one run of contiguous bytes (lz4.c:1168-1180); the one
+// difference kept is that a candidate in the block cannot be extended backwards into the segment (lowLimit, lz4.c:1065-1079).
+struct ExtEnc {
+    int pfx;                       // bytes of the segment in front of the block
+    uint32_t delta;                // liblz4 index of position 0
+    int prime;                     // 0: empty table; 1: LZ4_loadDict over the segment (lz4.c:1587-1646); 2: copy `table`
+    const uint32_t* table;         // prime 2: the dictionary context's table (liblz4 indices, LZ4_loadDictSlow; clz4.go:96-120)
+};
+
+template <bool U16, bool kExt = false>
 DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst,
-                             const int cap, const bool limited, void* tab)
+                             const int cap, const bool limited, void* tab, const ExtEnc x = ExtEnc{0, 0u, 0, nullptr})
 {
-    const int      sh      = (!U16 && n <= (1 << 22)) ? 10 : 0;
+    const int      P0      = kExt ? x.pfx : 0;                       // first position of the block
+    const uint32_t delta   = kExt ? x.delta : 0u;
+    const int      sh      = kExt ? (((uint32_t)n + delta <= (1u << 23)) ? 9 : 0) : ((!U16 && n <= (1 << 22)) ? 10 : 0);
     const uint32_t tagMask = (1u << sh) - 1u;
-    // fresh table per block (LZ4_initStream, lz4.c:1384): every slot = "position 0"
+    // fresh table per block (LZ4_initStream, lz4.c:1384): every slot = "index 0"
     {
-        const uint32_t e0 = (sh && n >= 4) ? (seq_tag(UNI(ld32u(src))) & tagMask) : 0u;
-        LANES({ uint32_t* t = (uint32_t*)tab; for (int i = LANE; i < kHashBytes / 4; i += 64) t[i] = e0; })
+        const uint32_t e0 = (sh && n >= 4 && delta == 0u) ? (seq_tag(UNI(ld32u(src))) & tagMask) : 0u;
+        uint32_t* t = (uint32_t*)tab;
+        if (kExt && x.prime == 2) {
+            // LZ4_memcpy(streamPtr, dictCtx) (lz4.c:1762-1768): liblz4 indices, tagged here with the bytes they point at
+            LANES({ for (int i = LANE; i < kHashBytes / 4; i += 64) {
+                const uint32_t idx = x.table[i];
+                t[i] = (idx >= delta && sh) ? ((idx << sh) | (seq_tag(ld32u(src + (idx - delta))) & tagMask)) : (idx << sh);
+            } })
+        } else {
+            LANES({ for (int i = LANE; i < kHashBytes / 4; i += 64) t[i] = e0; })
+        }
+        if (kExt && x.prime == 1) {
+            LDS_FENCE();
+            // LZ4_loadDict (lz4.c:1621-1628): every 3rd position of the segment, later entries overwrite earlier ones ==
+            // the largest index per slot
+            const int cnt = (x.pfx - 8) / 3 + 1;
+            LANES({ for (int k = LANE; k < cnt; k += 64) {
+                const uint64_t s8 = ld64u(src + 3 * k);
+                lds_max(&t[seq_hash<false>(s8)], (((uint32_t)(3 * k) + delta) << sh) | (seq_tag((uint32_t)s8) & tagMask));
+            } })
+        }
     }
     LDS_FENCE();
 
     const int lastProbe  = n - kMfLimit + 1;      // mflimitPlusOne (lz4.c:963)
     const int matchLimit = n - kLastLiterals;     // lz4.c:964
-    int anchor = 0, op = 0;
+    int anchor = P0, op = 0;
     STAT_DECL;
     const unsigned long long tBlock0 = STAT_NOW();
     (void)tBlock0;
 
-    if (n >= kMinLength) {
+    if (n - P0 >= kMinLength) {
         // Parser state between batches.
-        int  insPos  = 0;  bool hasIns = true;     // pending table insert ("First Byte" lz4.c:1005-1010; ip-2 lz4.c:1236-1242)
-        int  rePos   = 0;  bool hasRe  = false;    // pending immediate re-test at ip after a match (lz4.c:1255-1294)
-        int  sBase   = 1;  int  sIter  = 0;        // search started at sBase; next un-probed probe number
+        int  insPos  = P0; bool hasIns = true;     // pending table insert ("First Byte" lz4.c:1005-1010; ip-2 lz4.c:1236-1242)
+        int  rePos   = P0; bool hasRe  = false;    // pending immediate re-test at ip after a match (lz4.c:1255-1294)
+        int  sBase   = P0 + 1; int sIter = 0;      // search started at sBase; next un-probed probe number
         int  width   = 16;                         // generic batches: 16 lanes first, 64 when a search drags on
         LV(Win24, Pn); int prefBase = -1;          // next window's bytes, requested one batch ahead
         LV(Win24, Pc);                             // this window's bytes (kept: a wrong twin is repaired from them)
@@ -308,6 +344,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
         uint64_t pMm = 0; int pBase = 0, pAnchor0 = 0, pCur0 = 0; bool pRe0 = false;
         LV(int, pFwd); LV(int, pBck); LV(uint32_t, pR); LV(uint32_t, pLit8); LV(int, pStA); LV(int, pHasPm);
         LANES({ pFwd[I_] = 0; pBck[I_] = 0; pR[I_] = 0; pLit8[I_] = 0; pStA[I_] = 0; pHasPm[I_] = 0; })
+        // how far a candidate at position r may be extended backwards: to the start of what it lies in (lz4.c:1065-1079)
+        auto back_room = [&](uint32_t r) -> int { return (int)r - ((kExt && (int)r >= P0) ? P0 : 0); };
         // ---- 4. emit every recorded sequence of the pending batch at once, in two halves: emit_compute works out where
         // everything goes (no stores; false: liblz4 would return 0, limitedOutput), emit_store issues the stores.  Between
         // the two the grid batch waits for its candidate bytes: with the stores behind that wait, it is a wait for those loads
@@ -323,18 +361,18 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
             LANES({ anc[I_] = pHasPm[I_] ? base + pStA[I_] : anchor0; })
             {   // catch-up that may go past the 4 speculative bytes (rare): finish it now that the anchors are final
                 const uint64_t mmB = mm;
-                uint64_t deep = BALLOT(((mmB >> LANE) & 1) && pBck[I_] == 4 && min_(base + LANE - anc[I_], (int)pR[I_]) > 4);
+                uint64_t deep = BALLOT(((mmB >> LANE) & 1) && pBck[I_] == 4 && min_(base + LANE - anc[I_], back_room(pR[I_])) > 4);
                 for (; deep; deep &= deep - 1) {
                     const int w = ctz64(deep);
                     const int p0 = base + w, c0 = (int)RL(pR, w);
-                    const int maxBack = min_(p0 - RL(anc, w), c0);
+                    const int maxBack = min_(p0 - RL(anc, w), back_room((uint32_t)c0));
                     STAT(S_LONGBACK, 1);
                     WL(pBck, w, 4 + wave_common_back(src, p0 - 4, c0 - 4, maxBack - 4));
                 }
             }
             LANES({
                 const int q = base + LANE;
-                const int bk = min_(pBck[I_], min_(q - anc[I_], (int)pR[I_]));     // lz4.c:1105-1109 (0 for a re-test)
+                const int bk = min_(pBck[I_], min_(q - anc[I_], back_room(pR[I_])));     // lz4.c:1105-1109 (0 for a re-test)
                 pS[I_]   = q - bk;
                 lit[I_]  = q - bk - anc[I_];
                 mcT[I_]  = pFwd[I_] + bk;
@@ -424,10 +462,12 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         if (act[I_]) {
                             h[I_] = seq_hash<false>(win_seq(P));
                             const uint32_t tg = seq_tag(P.w[1]) & tagMask;
-                            ent[I_]  = ((uint32_t)q << sh) | tg;
+                            ent[I_]  = (((uint32_t)q + delta) << sh) | tg;
                             rent[I_] = lds_max_rtn(&T[h[I_]], ent[I_]);
-                            r[I_]    = rent[I_] >> sh;
-                            cand[I_] = !isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q && (rent[I_] & tagMask) == tg;
+                            const uint32_t ri = rent[I_] >> sh;
+                            const bool live = !kExt || ri >= delta;                      // dictSmall: an index below the segment (lz4.c:1085-1087)
+                            r[I_]    = live ? ri - delta : 0u;
+                            cand[I_] = !isIns && live && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q && (rent[I_] & tagMask) == tg;
                             if (cand[I_] && r[I_] >= 4) Cw[I_] = load_win24<false>(src, (int)r[I_]);
                         }
                         if (base + 160 <= n) Pn[I_] = load_win24<false>(src, q + 64);   // request the next window now, use it next batch
@@ -439,7 +479,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         if (act[I_] && cand[I_] && Cw[I_].w[1] == Pc[I_].w[1]) {
                             hit[I_] = 1;
                             fwd[I_] = win_fwd(Pc[I_], Cw[I_]);
-                            bck[I_] = min_(win_bck(Pc[I_], Cw[I_]), (int)r[I_]);
+                            bck[I_] = min_(win_bck(Pc[I_], Cw[I_]), back_room(r[I_]));
                         }
                         eLane[I_] = LANE + kMinMatch + fwd[I_];     // lane index just past a match that starts here
                     })
@@ -551,20 +591,21 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                     const int b = ctz64(bad);
                                     uint32_t ce = RL(rent, b);                          // entry lane b displaced
                                     for (;;) {
-                                        const uint32_t cp = ce >> sh;
-                                        if (cp < (uint32_t)firstPos) break;             // a pre-batch entry
-                                        const int t = (int)cp - base;
+                                        const uint32_t ci = ce >> sh;
+                                        if (ci < (uint32_t)firstPos + delta) break;     // a pre-batch entry
+                                        const int t = (int)(ci - delta) - base;
                                         if ((E >> t) & 1) break;                        // an executed lane of this batch
                                         ce = RL(rent, t);                               // a skipped lane: what it displaced
                                     }
-                                    const uint32_t cp = ce >> sh, qb = (uint32_t)(base + b);
+                                    const bool live = !kExt || (ce >> sh) >= delta;
+                                    const uint32_t cp = live ? (ce >> sh) - delta : 0u, qb = (uint32_t)(base + b);
                                     int nhit = 0, nfwd = 0, nbck = 0;
-                                    if (cp + kMaxDist >= qb && (ce & tagMask) == (RL(ent, b) & tagMask)) {
+                                    if (live && cp + kMaxDist >= qb && (ce & tagMask) == (RL(ent, b) & tagMask)) {
                                         Win24 Pb; for (int k = 0; k < 6; ++k) Pb.w[k] = RLF(Pc, w[k], b);
                                         Win24 Cw;
                                         if (cp >= (uint32_t)base) { const int t = (int)cp - base; for (int k = 0; k < 6; ++k) Cw.w[k] = RLF(Pc, w[k], t); }
                                         else { Cw = load_win24<true>(src, (int)cp); for (int k = 0; k < 6; ++k) Cw.w[k] = UNI(Cw.w[k]); }
-                                        if (Cw.w[1] == Pb.w[1]) { nhit = 1; nfwd = win_fwd(Pb, Cw); nbck = min_(win_bck(Pb, Cw), (int)cp); }
+                                        if (Cw.w[1] == Pb.w[1]) { nhit = 1; nfwd = win_fwd(Pb, Cw); nbck = min_(win_bck(Pb, Cw), back_room(cp)); }
                                     }
                                     WL(rent, b, ce); WL(r, b, cp); WL(hit, b, nhit); WL(fwd, b, nfwd); WL(bck, b, nbck);
                                     WL(eLane, b, b + kMinMatch + nfwd);
@@ -654,9 +695,9 @@ generic_batch:
                     const uint64_t s8 = ld64u(src + q[I_]);
                     lo4[I_] = (uint32_t)s8;
                     h[I_] = seq_hash<U16>(s8);
-                    ent[I_]  = ((uint32_t)q[I_] << sh) | (seq_tag(lo4[I_]) & tagMask);
+                    ent[I_]  = (((uint32_t)q[I_] + delta) << sh) | (seq_tag(lo4[I_]) & tagMask);
                     oldE[I_] = tab_get<U16>(tab, h[I_]);
-                    old[I_]  = oldE[I_] >> sh;
+                    old[I_]  = oldE[I_] >> sh;                                   // liblz4's index; a position once `delta` is taken off
                 }
             })
             LDS_FENCE();
@@ -667,7 +708,9 @@ generic_batch:
             LANES({
                 if (LANE < nproc && !(hasIns && LANE == 0)) {
                     const uint32_t cur = (uint32_t)q[I_];
-                    if ((U16 || old[I_] + kMaxDist >= cur) && ((oldE[I_] ^ ent[I_]) & tagMask) == 0)
+                    const bool live = !kExt || old[I_] >= delta;                 // dictSmall (lz4.c:1085-1087)
+                    old[I_] = live ? old[I_] - delta : 0u;
+                    if (live && (U16 || old[I_] + kMaxDist >= cur) && ((oldE[I_] ^ ent[I_]) & tagMask) == 0)
                         hit[I_] = (ld32u(src + old[I_]) == lo4[I_]);
                 }
             })
@@ -705,7 +748,7 @@ generic_batch:
 
             // catch-up over pending literals (lz4.c:1105-1109); a re-test has none (ip == anchor)
             if (!isRe) {
-                const int back = wave_common_back(src, p, c, min_(p - anchor, c));
+                const int back = wave_common_back(src, p, c, min_(p - anchor, back_room((uint32_t)c)));
                 p -= back; c -= back;
             }
 
@@ -986,6 +1029,21 @@ DEV int wave_encode_block_dict(const uint8_t* __restrict__ src, const int n, uin
         op += last;
     }
     return op;
+}
+
+// Every priming but the dictionary-context lookup (kDictCtxLookup, blocks <= 4 KiB: wave_encode_block_dict above) runs the
+// full encoder -- grid batches included -- in its external-segment mode: for kDictLoad / kDictCtxCopy the `segLen` bytes of the
+// previous block's tail / of the dictionary lie right before `blk` (the kernels copy them there).
+DEV int wave_encode_block_ext(const uint8_t* blk, const int n, uint8_t* __restrict__ dst, const int cap, const int mode,
+                              const int segLen, const uint32_t* dictTable, void* tab)
+{
+    if ((uint32_t)n > (uint32_t)kMaxInput) return 0;
+    if (n == 0) { if (cap <= 0) return 0; LANES({ if (LANE == 0) dst[0] = 0; }) return 1; }     // lz4.c:1361-1371 (always limitedOutput)
+    ExtEnc x{0, 0u, 0, nullptr};
+    if (mode == kDictNonePrefix) x.delta = 65536u;
+    else if (mode == kDictLoad)    { x.pfx = segLen; x.delta = 65536u - (uint32_t)segLen; x.prime = 1; }
+    else if (mode == kDictCtxCopy) { x.pfx = segLen; x.delta = 65536u - (uint32_t)segLen; x.prime = 2; x.table = dictTable; }
+    return wave_encode_block_tt<false, true>(blk - x.pfx, x.pfx + n, dst, cap, true, tab, x);
 }
 
 // ------------------------------------------------------------------------------------------ decoder

@@ -102,6 +102,22 @@ __global__ __launch_bounds__(64) void k_encode_rec(CodecArgs a)
     }
 }
 
+// One level-1 block under a dictionary context and/or after another linked block.  Every input block of such a call has
+// 64 KiB of scratch in front of it (host_codec lays the staging out that way): the external segment -- the previous block's
+// tail or the dictionary -- is copied there, right before the block, and the full encoder runs in its external-segment mode
+// (wave_encode_block_ext).  Only the dictionary-context lookup of blocks <= 4 KiB keeps the one-sequence-per-batch encoder.
+__device__ __forceinline__ int encode_block_primed(const uint8_t* s, int n, uint8_t* out, int cap, const DictEnc& dc, uint32_t* lds)
+{
+    if (dc.mode == kDictCtxLookup) return wave_encode_block_dict(s, n, out, cap, dc, lds);
+    int segLen = 0;
+    if (dc.mode == kDictLoad || dc.mode == kDictCtxCopy) {
+        segLen = dc.dictSize;
+        wave_copy(const_cast<uint8_t*>(s) - segLen, dc.dict, segLen);
+        WAVE_FENCE();
+    }
+    return wave_encode_block_ext(s, n, out, cap, dc.mode, segLen, dc.dictTable, lds);
+}
+
 // blk.CompressToBlk with a dictionary and/or linked blocks (config 5).  Which stream priming applies to a block follows
 // clz4.go:160-179 (StreamIndieCtx) and :224-248 (StreamLinkedCtx) + async/writer.go:412-437 (_genDict).
 __global__ __launch_bounds__(64) void k_encode_rec_dict(CodecArgs a)
@@ -124,7 +140,7 @@ __global__ __launch_bounds__(64) void k_encode_rec_dict(CodecArgs a)
             if (a.dictLen >= 8) { dc.dict = a.dict; dc.dictSize = a.dictLen; dc.dictTable = a.dictTable; dc.mode = n > 4096 ? kDictCtxCopy : kDictCtxLookup; }
             else dc.mode = kDictNonePrefix;
         }                                                     // else: linked frame start without dictionary -> kDictFreshPrefix
-        int      c    = wave_encode_block_dict(s, n, rec + 4, a.bsz, dc, lds);
+        int      c    = encode_block_primed(s, n, rec + 4, a.bsz, dc, lds);
         uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
         if (c == 0) { wave_copy(rec + 4, s, n); c = n; word = 0x80000000u | ((uint32_t)n & 0x7FFFFFFFu); }
         int len = c + 4;
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(64) void k_encode_raw_dict(CodecArgs a)
         DictEnc dc{nullptr, 0, kDictNonePrefix, nullptr};
         if (a.dictLen >= 8) { dc.dict = a.dict; dc.dictSize = a.dictLen; dc.dictTable = a.dictTable; dc.mode = n > 4096 ? kDictCtxCopy : kDictCtxLookup; }
         const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
-        const int r = wave_encode_block_dict(a.src + (int64_t)i * a.srcStride, n, a.dst + (int64_t)i * a.dstStride, cap, dc, lds);
+        const int r = encode_block_primed(a.src + (int64_t)i * a.srcStride, n, a.dst + (int64_t)i * a.dstStride, cap, dc, lds);
         if ((threadIdx.x & 63u) == 0) a.result[i] = r;
     }
 }
@@ -793,13 +809,16 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     HIPCHK(c, hipSetDevice(c->device));
     const bool dictMode = dj && dj->any;
     const bool hcMode = dj && is_hc_level(dj->level);
-    const bool chained = dictMode && dj->linked;
+    // a linked DECODE is one serial chain (block i needs block i-1's output): one chunk.  A linked ENCODE needs only the
+    // previous block's source tail, which the caller's buffers hold: it is cut into chunks like any other call, the first
+    // block of a later chunk getting the tail of the block before it as its prevTail.
+    const bool chained = dictMode && dj->linked && mode == 3;
     if (hcMode) { if (int rc = ensure_hc(c)) return rc; }
     if (dictMode && dj->prevTail && dj->prevTailLen > 65536) return fail(c, PLZ4HIP_E_ARG, "prevTail longer than 64 KiB");
 
     size_t kChunkBytes = (size_t)6 << 30;      // x kSlots in flight: enough blocks for every encoder wave slot at 4 MiB blocks
     if (const char* v = getenv("PLZ4HIP_HOST_CHUNK_MB")) { const long mb = atol(v); if (mb > 0) kChunkBytes = (size_t)mb << 20; }   // tests: force many chunks
-    const size_t gap = (hcMode && dictMode) ? 65536 : 0;
+    const size_t gap = (dictMode && (mode == 0 || mode == 2)) ? 65536 : 0;     // encoders with a dictionary / linked blocks: room for the external segment
     int cb = nBlocks;
     {
         const Staging one = plan(1, maxIn, maxOut, gap);
@@ -845,10 +864,15 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
                 }
             }
             a.linked = dj->linked;
-            if (dj->prevTail && dj->prevTailLen >= 0) {
-                memcpy(sl.h + offExtra, dj->prevTail, (size_t)dj->prevTailLen);
-                HIPCHK(c, hipMemcpyAsync(sl.d + offExtra, sl.h + offExtra, (size_t)dj->prevTailLen + 16, hipMemcpyHostToDevice, s));
-                a.prevTail = sl.d + offExtra; a.prevTailLen = dj->prevTailLen;
+            const void* pt = dj->prevTail; int ptLen = (dj->prevTail && dj->prevTailLen >= 0) ? dj->prevTailLen : -1;
+            if (dj->linked && b0 > 0) {                                   // a later chunk of a linked encode
+                const int pl = srcLen[b0 - 1]; ptLen = pl < 65536 ? pl : 65536;
+                pt = (const uint8_t*)src[b0 - 1] + (pl - ptLen);
+            }
+            if (ptLen >= 0) {
+                if (ptLen) memcpy(sl.h + offExtra, pt, (size_t)ptLen);
+                HIPCHK(c, hipMemcpyAsync(sl.d + offExtra, sl.h + offExtra, (size_t)ptLen + 16, hipMemcpyHostToDevice, s));
+                a.prevTail = sl.d + offExtra; a.prevTailLen = ptLen;
             }
             if (dj->window) {
                 memcpy(sl.h + offExtra + 65536, dj->window, 65536);

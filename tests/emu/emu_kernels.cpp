@@ -7,10 +7,12 @@
 #include <stdlib.h>
 
 int plz4_emu_descending = 0;
+static int plz4_emu_old_dict = 0;      // 1: every dictionary mode through the one-sequence-per-batch encoder (cross-check)
 
 extern "C" {
 
 void emu_set_descending(int d) { plz4_emu_descending = d; }
+void emu_set_old_dict(int d) { plz4_emu_old_dict = d; }
 
 int emu_encode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
 {
@@ -81,8 +83,20 @@ int emu_encode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, cons
                           const uint32_t* dictTable)
 {
     static thread_local uint32_t lds[plz4::kHashBytes / 4];
-    plz4::DictEnc dc{dict, dictSize, mode, dictTable};
-    return plz4::wave_encode_block_dict(src, n, dst, cap, dc, lds);
+    if (mode == plz4::kDictCtxLookup || plz4_emu_old_dict) {
+        plz4::DictEnc dc{dict, dictSize, mode, dictTable};
+        return plz4::wave_encode_block_dict(src, n, dst, cap, dc, lds);
+    }
+    // as the kernels do: the segment is laid out right before (a copy of) the block
+    const bool seg = (mode == plz4::kDictLoad || mode == plz4::kDictCtxCopy);
+    const int segLen = seg ? dictSize : 0;
+    uint8_t* cat = (uint8_t*)malloc((size_t)segLen + (size_t)n + 64);
+    if (segLen) memcpy(cat, dict, (size_t)segLen);
+    if (n) memcpy(cat + segLen, src, (size_t)n);
+    memset(cat + segLen + n, 0, 64);
+    const int r = plz4::wave_encode_block_ext(cat + segLen, n, dst, cap, mode, segLen, dictTable, lds);
+    free(cat);
+    return r;
 }
 
 int emu_decode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, const uint8_t* dict, int dictSize)

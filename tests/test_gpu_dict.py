@@ -126,3 +126,27 @@ def test_gpu_indie_frame_with_dictionary(orc, eng):
     for b, o in zip(blocks, outs):
         assert np.array_equal(b, o)
     eng.dict_destroy(d)
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_gpu_linked_encode_in_many_chunks(orc, level, monkeypatch):
+    """A linked encode is cut into staging chunks like any other host call (the first block of a later chunk is primed with
+    the tail of the block before it, taken from the caller's buffers): the records must not depend on the chunk size."""
+    from plz4_amd._native import Engine
+    bsz = 64 << 10
+    user = synth.text(70000, seed=42)
+    data = synth.make("M", 37 * bsz + 555, bsz, seed=15)
+    blocks = [np.ascontiguousarray(data[o:o + bsz]) for o in range(0, data.size, bsz)]
+    blocks.insert(9, np.ascontiguousarray(data[:5]))                  # a short flush block: the next block's window is 5 bytes
+    e = Engine(0); d = e.dict_create(np.ascontiguousarray(user))
+    whole = e.encode_records_ex(blocks, bsz, True, linked=True, d=d, level=level)
+    monkeypatch.setenv("PLZ4HIP_HOST_CHUNK_MB", "1")
+    parts = e.encode_records_ex(blocks, bsz, True, linked=True, d=d, level=level)
+    assert [r.tobytes() for r in parts] == [r.tobytes() for r in whole]
+    if level == 1:
+        prev = None
+        for b, g in zip(blocks, whole):
+            tail = None if prev is None else prev[-65536:].copy()
+            r, c = orc.compress_linked(b, bsz, tail, orc.dict_ctx(user) if prev is None else None)
+            assert g.tobytes() == _record(orc, r, c, b, True); prev = b
+    e.dict_destroy(d); e.close()
