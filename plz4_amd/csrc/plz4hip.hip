@@ -169,7 +169,7 @@ __global__ __launch_bounds__(64) void k_encode_raw_dict(CodecArgs a)
 }
 
 // One record against an optional dictionary; shared by the independent and the linked decode kernels.
-__device__ __forceinline__ void decode_one_record(const CodecArgs& a, int i, const uint8_t* dict, int dictLen, int* rOut, int* stOut, bool* stored)
+__device__ __forceinline__ void decode_one_record(const CodecArgs& a, int i, const uint8_t* dict, int dictLen, int* rOut, int* stOut, bool* stored, uint8_t* dl)
 {
     const uint8_t* rec    = a.recOff ? a.src + a.recOff[i] : a.src + (int64_t)i * a.srcStride;
     const int64_t  recLen = a.recOff ? a.recOff[i + 1] - a.recOff[i] : (int64_t)a.srcLen[i];
@@ -190,7 +190,7 @@ __device__ __forceinline__ void decode_one_record(const CodecArgs& a, int i, con
                 if (sz > a.dstCapAll) st = PLZ4HIP_BLK_SIZE_OVERFLOW;
                 else { wave_copy(out, rec + 4, sz); r = sz; *stored = true; }
             } else {
-                r = wave_decode_block(rec + 4, sz, out, a.dstCapAll, dict, dictLen);
+                r = wave_decode_block<true>(rec + 4, sz, out, a.dstCapAll, dict, dictLen, dl);    // the batches are assembled in LDS, as in k_decode_rec
                 if (r < 0) st = PLZ4HIP_BLK_CORRUPT;
             }
         }
@@ -201,9 +201,10 @@ __device__ __forceinline__ void decode_one_record(const CodecArgs& a, int i, con
 // Independent blocks with a dictionary (indieDecompressorWithDict, compress/decompress.go:42-58, linked == false).
 __global__ __launch_bounds__(64) void k_decode_rec_dict(CodecArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t dl[kDecLdsBytes];
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
         int r, st; bool stored;
-        decode_one_record(a, i, a.dict, a.dictLen, &r, &st, &stored);
+        decode_one_record(a, i, a.dict, a.dictLen, &r, &st, &stored, dl);
         if ((threadIdx.x & 63u) == 0) { a.result[i] = r; a.status[i] = st; }
     }
 }
@@ -212,12 +213,13 @@ __global__ __launch_bounds__(64) void k_decode_rec_dict(CodecArgs a)
 // NOT updated by stored blocks (sync/reader.go:75-78, async/reader.go:149-163) -- the reference's behaviour, kept.
 __global__ __launch_bounds__(64) void k_decode_rec_linked(CodecArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t dl[kDecLdsBytes];
     uint8_t* winA = a.window; uint8_t* winB = a.window + 65536;
     int winLen = *a.windowLen;
     bool dead = false;
     for (int i = 0; i < a.nBlocks; ++i) {
         int r = 0, st = PLZ4HIP_BLK_CORRUPT; bool stored = false;
-        if (!dead) decode_one_record(a, i, winA, winLen, &r, &st, &stored);
+        if (!dead) decode_one_record(a, i, winA, winLen, &r, &st, &stored, dl);
         if ((threadIdx.x & 63u) == 0) { a.result[i] = r; a.status[i] = st; }
         if (st != PLZ4HIP_BLK_OK) { dead = true; continue; }             // first error ends the stream
         if (stored) continue;

@@ -99,9 +99,17 @@ int emu_encode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, cons
     return r;
 }
 
+// With a dictionary too, both builds of the vector path must agree (the record kernels run the LDS-staged one).
 int emu_decode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, const uint8_t* dict, int dictSize)
 {
-    return plz4::wave_decode_block(src, n, dst, cap, dict, dictSize);
+    static thread_local uint8_t lds[plz4::kDecLdsBytes];
+    const int r1 = plz4::wave_decode_block<true>(src, n, dst, cap, dict, dictSize, lds);
+    uint8_t* alt = (uint8_t*)malloc((size_t)(cap > 0 ? cap : 1) + 64);
+    memset(alt, 0, (size_t)(cap > 0 ? cap : 1) + 64);
+    const int r2 = plz4::wave_decode_block<false>(src, n, alt, cap, dict, dictSize);
+    const bool same = (r1 == r2) && (r1 <= 0 || memcmp(dst, alt, (size_t)r1) == 0);
+    free(alt);
+    return same ? r1 : -999999;
 }
 
 }
