@@ -1,4 +1,5 @@
-// Diagnostics: how many one-wave workgroups with L bytes of LDS are really co-resident, and where the dispatcher puts them.
+// Diagnostics: how many workgroups (T threads, L bytes of LDS) are really co-resident, and where the dispatcher puts them.
+// usage: residency [grid] [ldsBytes] [threads]
 // Each workgroup records its start time (100 MHz wall clock), HW_ID and XCC_ID, then spins for ~20 ms.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -19,11 +20,12 @@ __global__ void k(unsigned long long* out, int spinTicks)
 }
 int main(int argc, char** argv)
 {
-    const int grid = argc > 1 ? atoi(argv[1]) : 2560, ldsBytes = argc > 2 ? atoi(argv[2]) : 16384;
+    const int grid = argc > 1 ? atoi(argv[1]) : 2560, ldsBytes = argc > 2 ? atoi(argv[2]) : 16384, threads = argc > 3 ? atoi(argv[3]) : 64;
     unsigned long long* d; hipMalloc(&d, grid * 24);
     hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);
-    int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 64, ldsBytes);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64), ldsBytes, 0, d, 2000000);
+    int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, threads, ldsBytes);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), ldsBytes, 0, d, 2000000);
+    if (hipGetLastError() != hipSuccess) { printf("launch failed (threads %d, lds %d)\n", threads, ldsBytes); return 1; }
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(grid * 3); hipMemcpy(h.data(), d, grid * 24, hipMemcpyDeviceToHost);
     unsigned long long tmin = ~0ull; for (int i = 0; i < grid; i++) tmin = std::min(tmin, h[i * 3]);
@@ -36,7 +38,7 @@ int main(int argc, char** argv)
         if (e) perCu[(xcc << 12) | (se << 8) | (sh << 4) | cu]++;
     }
     std::map<int, int> hist; for (auto& kv : perCu) hist[kv.second]++;
-    printf("grid %d lds %d: occupancy API %d/CU; started in the first 10 ms: %d on %zu CUs; per-CU histogram:", grid, ldsBytes, occ, early, perCu.size());
+    printf("grid %d lds %d threads %d: occupancy API %d/CU; started in the first 10 ms: %d on %zu CUs; per-CU histogram:", grid, ldsBytes, threads, occ, early, perCu.size());
     for (auto& kv : hist) printf(" %dx%d", kv.second, kv.first);
     printf("\n");
     return 0;
