@@ -500,6 +500,7 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         const unsigned long long tg1 = STAT_NOW(); (void)tg1;
                         STAT(S_CYC_LOAD, tg1 - tg0);
                         uint64_t twins = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);          // earlier twin inside this batch
+                        uint64_t cwValid = BALLOT(act[I_] && cand[I_]);       // lanes whose Cw holds the window of their rent's position
                         const uint64_t anyTwins = twins;                                          // (bits of repaired lanes get cleared below)
                         uint64_t specialLeft = BALLOT(hit[I_] && fwd[I_] == 16);           // longer than the speculative window: the hop needs its end
                         const int  cur0 = probeStart - base;                  // first probe lane (>= 64: none in this batch)
@@ -514,6 +515,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                         int      Send = 0;
                         bool     finished = false;
                         LV(int, stA); LV(int, hasPm);
+                        // after a twin repair at lane b the walk is redone from b only: what it did below b does not depend on b
+                        uint64_t keep = 0; int resume = -1;
                         for (;;) {
                             const unsigned long long th0 = STAT_NOW(); (void)th0;
                             LV(int, nextHit);      // first recorded match at or after the end of the match that starts here (64: none)
@@ -524,12 +527,15 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                     nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
                                 })
                             }
-                            mm = 0; eL = 0; finished = false;
+                            mm = keep; eL = 0; finished = false;
                             const unsigned long long th1 = STAT_NOW(); (void)th1;
                             STAT(S_DBATCH, th1 - th0);
                             int w = 64;
-                            if (cur0 < 64) { const uint64_t hm = hits & (~0ull << cur0); if (hm) w = ctz64(hm); }
-                            if (w < 64 && w <= lim0) {
+                            {
+                                const int start = resume >= 0 ? resume : cur0;     // lane b was a probe: the parser is searching there
+                                if (start < 64) { const uint64_t hm = hits & (~0ull << start); if (hm) w = ctz64(hm); }
+                            }
+                            if (w < 64 && (mm != 0 || w <= lim0)) {               // (the stride limit concerns the first match only)
                                 // Hops come four to a branch (a taken branch costs more than the hop).  A hop is: mark the lane,
                                 // fetch its successor.  Once the walk has ended (w == 64) the remaining hops of a group only
                                 // touch bit 0 of the mask, which no hop but the very first can legitimately set.
@@ -561,8 +567,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                     w = hm ? ctz64(hm) : 64;
                                     if (w >= 64) break;
                                 }
-                                eL = RL(eLane, 63 - __builtin_clzll(mm));       // mm != 0 here: the first hop always marks
                             }
+                            if (mm) eL = RL(eLane, 63 - __builtin_clzll(mm));
                             // ---- 3. which lanes did the sequential parser execute
                             const unsigned long long th2 = STAT_NOW(); (void)th2;
                             STAT(S_DMEMB, th2 - th1);
@@ -590,22 +596,27 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                     STAT(S_TWINSTOP, 1);
                                     const int b = ctz64(bad);
                                     uint32_t ce = RL(rent, b);                          // entry lane b displaced
+                                    int tl = -1;                                        // the lane whose displaced entry `ce` is
                                     for (;;) {
                                         const uint32_t ci = ce >> sh;
                                         if (ci < (uint32_t)firstPos + delta) break;     // a pre-batch entry
                                         const int t = (int)(ci - delta) - base;
                                         if ((E >> t) & 1) break;                        // an executed lane of this batch
                                         ce = RL(rent, t);                               // a skipped lane: what it displaced
+                                        tl = t;
                                     }
                                     const bool live = !kExt || (ce >> sh) >= delta;
                                     const uint32_t cp = live ? (ce >> sh) - delta : 0u, qb = (uint32_t)(base + b);
                                     int nhit = 0, nfwd = 0, nbck = 0;
                                     if (live && cp + kMaxDist >= qb && (ce & tagMask) == (RL(ent, b) & tagMask)) {
                                         Win24 Pb; for (int k = 0; k < 6; ++k) Pb.w[k] = RLF(Pc, w[k], b);
-                                        Win24 Cw;
-                                        if (cp >= (uint32_t)base) { const int t = (int)cp - base; for (int k = 0; k < 6; ++k) Cw.w[k] = RLF(Pc, w[k], t); }
-                                        else { Cw = load_win24<true>(src, (int)cp); for (int k = 0; k < 6; ++k) Cw.w[k] = UNI(Cw.w[k]); }
-                                        if (Cw.w[1] == Pb.w[1]) { nhit = 1; nfwd = win_fwd(Pb, Cw); nbck = min_(win_bck(Pb, Cw), back_room(cp)); }
+                                        Win24 Cn;
+                                        if (cp >= (uint32_t)base) { const int t = (int)cp - base; for (int k = 0; k < 6; ++k) Cn.w[k] = RLF(Pc, w[k], t); }
+                                        // a pre-batch entry was displaced by lane tl, and if that lane took it for a candidate (a twin
+                                        // usually repeats the very same bytes) its window already holds what is needed: no memory round trip
+                                        else if (tl >= 0 && ((cwValid >> tl) & 1) && cp >= 4) { STAT(S_MEMLIT, 0); for (int k = 0; k < 6; ++k) Cn.w[k] = RLF(Cw, w[k], tl); }
+                                        else { Cn = load_win24<true>(src, (int)cp); for (int k = 0; k < 6; ++k) Cn.w[k] = UNI(Cn.w[k]); }
+                                        if (Cn.w[1] == Pb.w[1]) { nhit = 1; nfwd = win_fwd(Pb, Cn); nbck = min_(win_bck(Pb, Cn), back_room(cp)); }
                                     }
                                     WL(rent, b, ce); WL(r, b, cp); WL(hit, b, nhit); WL(fwd, b, nfwd); WL(bck, b, nbck);
                                     WL(eLane, b, b + kMinMatch + nfwd);
@@ -613,6 +624,8 @@ DEV int wave_encode_block_tt(const uint8_t* __restrict__ src, const int n, uint8
                                     hits = nhit ? (hits | bit) : (hits & ~bit);
                                     specialLeft = (nhit && nfwd == 16) ? (specialLeft | bit) : (specialLeft & ~bit);
                                     twins &= ~bit;
+                                    cwValid &= ~bit;                                    // lane b's Cw no longer belongs to its (new) rent
+                                    keep = mm & (bit - 1); resume = b;
                                     STAT(S_DSEQ_ML15, STAT_NOW() - th3);
                                     continue;
                                 }
