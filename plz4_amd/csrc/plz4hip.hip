@@ -68,16 +68,16 @@ __device__ __forceinline__ int block_len(const CodecArgs& a, int i)
 // workgroup owns all 160 KiB of a CU's LDS, i.e. ten tables per CU, where one-wave workgroups of 16 KiB only reach nine per CU
 // (scripts/micro/residency.hip: "2560 16384 64" -> 9 per CU; two 80 KiB workgroups of five waves do not co-reside either --
 // measured on k_encode_rec: the second one waits for the first).  The waves of a workgroup never synchronise; each pulls block
-// ids from the queue until it is empty.  A call with fewer blocks than wave slots launches fewer waves per workgroup, so that
-// its blocks still spread over all CUs (enc_launch).
+// ids from the queue until it is empty.  Only a call that fills the chip by itself is launched that way: a smaller one (the
+// chunks of a host call, several of which share the GPU) keeps one-wave workgroups of 16 KiB, which leave the rest of a CU's
+// LDS to other kernels -- hence the two instantiations of every encoder kernel (W = waves per workgroup).
 constexpr int kEncWavesPerWg = 10;
-constexpr int kEncWgThreads  = 64 * kEncWavesPerWg;
 #define ENC_WAVE_TABLE(name) \
-    __shared__ uint32_t name##_all[kEncWavesPerWg][kHashBytes / 4]; \
-    uint32_t* const name = name##_all[plz4_readfirstlane((int)(threadIdx.x >> 6))]
+    __shared__ uint32_t name##_all[W][kHashBytes / 4]; \
+    uint32_t* const name = name##_all[W == 1 ? 0 : plz4_readfirstlane((int)(threadIdx.x >> 6))]
 
 // LZ4 blocks only: dst[i] <- LZ4_compress_fast(src[i]), result[i] = bytes or 0.
-__global__ __launch_bounds__(kEncWgThreads) void k_encode_raw(CodecArgs a)
+template <int W> __global__ __launch_bounds__(64 * W) void k_encode_raw(CodecArgs a)
 {
     ENC_WAVE_TABLE(lds);
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kEncWgThreads) void k_encode_raw(CodecArgs a)
 }
 
 // blk.CompressToBlk on the device: [LE32 size|stored][payload][LE32 xxh32?] at dst + i*dstStride.
-__global__ __launch_bounds__(kEncWgThreads) void k_encode_rec(CodecArgs a)
+template <int W> __global__ __launch_bounds__(64 * W) void k_encode_rec(CodecArgs a)
 {
     ENC_WAVE_TABLE(lds);
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
@@ -132,7 +132,7 @@ __device__ __forceinline__ int encode_block_primed(const uint8_t* s, int n, uint
 
 // blk.CompressToBlk with a dictionary and/or linked blocks (config 5).  Which stream priming applies to a block follows
 // clz4.go:160-179 (StreamIndieCtx) and :224-248 (StreamLinkedCtx) + async/writer.go:412-437 (_genDict).
-__global__ __launch_bounds__(kEncWgThreads) void k_encode_rec_dict(CodecArgs a)
+template <int W> __global__ __launch_bounds__(64 * W) void k_encode_rec_dict(CodecArgs a)
 {
     ENC_WAVE_TABLE(lds);
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kEncWgThreads) void k_encode_rec_dict(CodecArgs a)
 }
 
 // Raw LZ4 blocks with a dictionary context (StreamIndieCtx): the block API with WithBlockDictionary (plz4_block.go:48-53).
-__global__ __launch_bounds__(kEncWgThreads) void k_encode_raw_dict(CodecArgs a)
+template <int W> __global__ __launch_bounds__(64 * W) void k_encode_raw_dict(CodecArgs a)
 {
     ENC_WAVE_TABLE(lds);
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
@@ -548,15 +548,13 @@ template <class F> void parallel_blocks(int n, size_t totalBytes, F&& fn)
 
 int grid_for(int nBlocks, int resident) { return nBlocks < resident ? nBlocks : resident; }
 // workgroups of the level-1 encoder kernels (kEncWavesPerWg waves each) for nBlocks blocks and `resident` resident waves
-struct EncLaunch { int grid, threads; };
-EncLaunch enc_launch(int nBlocks, int resident, int cus)
-{
-    const int waves = grid_for(nBlocks, resident);
-    int per = (waves + cus - 1) / cus;                       // waves per workgroup: as few as spread the blocks over every CU
-    if (per < 1) per = 1;
-    if (per > kEncWavesPerWg) per = kEncWavesPerWg;
-    return EncLaunch{(waves + per - 1) / per, 64 * per};
-}
+// Launch of a level-1 encoder kernel: ten-wave workgroups when the call has more blocks than nine-per-CU one-wave workgroups
+// could hold at once, one-wave workgroups otherwise.
+#define ENC_LAUNCH(kernel, nBlocks, c, s, a) do { \
+        const int waves_ = grid_for((nBlocks), (c)->encWaves); \
+        if (waves_ > 9 * (c)->cus) hipLaunchKernelGGL(kernel<kEncWavesPerWg>, dim3((waves_ + kEncWavesPerWg - 1) / kEncWavesPerWg), dim3(64 * kEncWavesPerWg), 0, s, a); \
+        else hipLaunchKernelGGL(kernel<1>, dim3(waves_), dim3(64), 0, s, a); \
+    } while (0)
 
 bool is_hc_level(int level) { return level >= 2 && level <= 12; }        // every row of the level table (lz4hc.c:92-106): mid, hash chain, optimal
 
@@ -618,7 +616,7 @@ int plz4hip_ctx_create(int device, plz4hip_ctx** out)
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_queues, kQueueSlots * sizeof(uint32_t));
     if (e == hipSuccess) e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device);
     int encPer = 0, decPer = 0;
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&encPer, k_encode_rec, kEncWgThreads, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&encPer, k_encode_rec<kEncWavesPerWg>, 64 * kEncWavesPerWg, 0);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&decPer, k_decode_rec, 64, 0);
     if (e != hipSuccess) {
         fprintf(stderr, "plz4hip_ctx_create: %s\n", hipGetErrorString(e));
@@ -670,7 +668,7 @@ int plz4hip_dev_compress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t s
     a.src = (const uint8_t*)src; a.srcStride = srcStride; a.srcLen = srcLen;
     a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCap = dstCap;
     a.result = result; a.queue = q; a.nBlocks = nBlocks;
-    { const EncLaunch el = enc_launch(nBlocks, c->encWaves, c->cus); hipLaunchKernelGGL(k_encode_raw, dim3(el.grid), dim3(el.threads), 0, s, a); }
+    ENC_LAUNCH(k_encode_raw, nBlocks, c, s, a);
     HIPCHK(c, hipGetLastError());
     return PLZ4HIP_OK;
 }
@@ -715,7 +713,7 @@ int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes
         a.level = level; a.hcWork = c->d_hc;
         hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nBlocks, c->hcWaves)), dim3(64), 0, s, a);
     } else {
-        { const EncLaunch el = enc_launch(nBlocks, c->encWaves, c->cus); hipLaunchKernelGGL(k_encode_rec, dim3(el.grid), dim3(el.threads), 0, s, a); }
+        ENC_LAUNCH(k_encode_rec, nBlocks, c, s, a);
     }
     HIPCHK(c, hipGetLastError());
     return PLZ4HIP_OK;
@@ -905,14 +903,14 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         }
         switch (mode) {
         case 0: if (hcMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
-                else if (dictMode) { const EncLaunch el = enc_launch(nb, c->encWaves, c->cus); hipLaunchKernelGGL(k_encode_raw_dict, dim3(el.grid), dim3(el.threads), 0, s, a); }
-                else { const EncLaunch el = enc_launch(nb, c->encWaves, c->cus); hipLaunchKernelGGL(k_encode_raw, dim3(el.grid), dim3(el.threads), 0, s, a); } break;
+                else if (dictMode) ENC_LAUNCH(k_encode_raw_dict, nb, c, s, a);
+                else ENC_LAUNCH(k_encode_raw, nb, c, s, a); break;
         case 1: if (dictMode) hipLaunchKernelGGL(k_decode_raw_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
                 else hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a); break;
         case 2: a.dstCap = nullptr;
                 if (hcMode) hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
-                else if (dictMode) { const EncLaunch el = enc_launch(nb, c->encWaves, c->cus); hipLaunchKernelGGL(k_encode_rec_dict, dim3(el.grid), dim3(el.threads), 0, s, a); }
-                else { const EncLaunch el = enc_launch(nb, c->encWaves, c->cus); hipLaunchKernelGGL(k_encode_rec, dim3(el.grid), dim3(el.threads), 0, s, a); } break;
+                else if (dictMode) ENC_LAUNCH(k_encode_rec_dict, nb, c, s, a);
+                else ENC_LAUNCH(k_encode_rec, nb, c, s, a); break;
         case 3: a.dstCap = nullptr;
                 if (dictMode && dj->linked) hipLaunchKernelGGL(k_decode_rec_linked, dim3(1), dim3(64), 0, s, a);
                 else if (dictMode) hipLaunchKernelGGL(k_decode_rec_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
