@@ -133,6 +133,8 @@ DEV bool hc_protect(uint32_t prefixIdx, uint32_t mi) { return (uint32_t)((prefix
 
 // LZ4HC_InsertAndGetWiderMatch (lz4hc.c:884-1104): `lowLimit` is iLowLimit (how far the match may be extended backwards),
 // `longest` the length to beat, patternAnalysis / chainSwap as in the reference.  Positions count from s.src.
+// kD = false: an independent block without a dictionary (no segment, no context): every branch for those folds away.
+template <bool kD>
 DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches,
                           bool patternAnalysis, bool chainSwap)
 {
@@ -140,8 +142,9 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
     const uint8_t* const ip = src + pos;
     const uint8_t* const iLow = src + lowLimit;
     const uint8_t* const iHigh = src + highLimit;
-    const uint8_t* const prefixPtr = src + s.pfx;
-    const uint32_t prefixIdx = kHcBase + (uint32_t)s.pfx;
+    const int pfx = kD ? s.pfx : 0;
+    const uint8_t* const prefixPtr = src + pfx;
+    const uint32_t prefixIdx = kHcBase + (uint32_t)pfx;
     const uint32_t ipIndex = (uint32_t)pos + kHcBase;
     const bool     within = kHcBase + 65536u > ipIndex;                                         // withinStartDistance, :898
     const uint32_t lowest = within ? kHcBase : ipIndex - 65535u;                                 // :899
@@ -161,7 +164,7 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
         attempts--;
         {
             const uint8_t* const mp = src + (mi - kHcBase);
-            if (mi >= prefixIdx) {                                                               // within the prefix, :925-939
+            if (!kD || mi >= prefixIdx) {                                                        // within the prefix, :925-939
                 if (ld16u(iLow + longest - 1) == ld16u(mp - lookBack + longest - 1)) {
                     if (ld32u(mp) == pattern) {
                         const int back = lookBack ? hc_count_back(ip, mp, iLow, prefixPtr) : 0;
@@ -205,7 +208,7 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
                         srcPatternLength = hc_count_pattern(ip + 4, iHigh, pattern) + 4;
                     } else repeat = 1;
                 }
-                if (repeat == 2 && mci >= lowest && hc_protect(prefixIdx, mci)) {
+                if (repeat == 2 && mci >= lowest && (!kD || hc_protect(prefixIdx, mci))) {
                     const uint8_t* const mp = src + (mci - kHcBase);
                     if (ld32u(mp) == pattern) {
                         // forward to the segment's end and on into the prefix with the rotated pattern (:1009-1013), backwards
@@ -217,10 +220,10 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
                         const size_t seg = back + fwd;
                         if (seg >= srcPatternLength && fwd <= srcPatternLength) {
                             const uint32_t nmi = mci + (uint32_t)fwd - (uint32_t)srcPatternLength;   // :1027-1036
-                            mi = hc_protect(prefixIdx, nmi) ? nmi : prefixIdx;
+                            mi = (!kD || hc_protect(prefixIdx, nmi)) ? nmi : prefixIdx;
                         } else {
                             const uint32_t nmi = mci - (uint32_t)back;                           // :1038-1058
-                            if (!hc_protect(prefixIdx, nmi)) mi = prefixIdx;
+                            if (kD && !hc_protect(prefixIdx, nmi)) mi = prefixIdx;
                             else {
                                 mi = nmi;
                                 if (lookBack == 0) {
@@ -243,7 +246,7 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
         }
         mi -= s.w.chain[(mi + chainPos) & 0xFFFFu];                                              // :1065
     }
-    if (s.d.mode == kHcCtx && attempts > 0 && within) {                                          // usingDictCtxHc, :1069-1098
+    if (kD && s.d.mode == kHcCtx && attempts > 0 && within) {                                          // usingDictCtxHc, :1069-1098
         const uint32_t dictEnd = kHcBase + (uint32_t)s.d.len;        // the context's end index: its own indices start at 64 KiB
         uint32_t dmi = s.d.hash[hc_hash(ip)];
         mi = dmi + lowest - dictEnd;
@@ -266,9 +269,10 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
 }
 
 // LZ4HC_FindLongerMatch (lz4hc.c:1802-1820): forward-only search with pattern analysis and chain swap
+template <bool kD>
 DEV HcMatch hc_find_longer(HcState& s, int pos, int highLimit, int minLen, int nbSearches)
 {
-    HcMatch m = hc_find_wider(s, pos, pos, highLimit, minLen, nbSearches, true, true);
+    HcMatch m = hc_find_wider<kD>(s, pos, pos, highLimit, minLen, nbSearches, true, true);
     if (m.len <= minLen) { m.len = 0; m.off = 0; }                                               // :1815
     return m;
 }
@@ -369,12 +373,14 @@ DEV void hc_prime(HcState& s, int level)
 
 // Levels 3..9: LZ4HC_compress_hashChain (lz4hc.c:1121-1363), nbSearches = 1 << (level - 1) (table :92-106),
 // patternAnalysis only above 128 attempts (level 9).  The goto structure of the reference is kept: it IS the algorithm.
-DEV int hc_compress_chain(const uint8_t* src, const int pfx, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w, const HcDict& d)
+template <bool kD>
+DEV int hc_compress_chain(const uint8_t* src, const int pfxArg, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w, const HcDict& d)
 {
     if ((uint32_t)n > (uint32_t)kMaxInput) return 0;                                             // :1388
     const bool limited = cap < compress_bound(n);
     const int  maxNb = 1 << (level - 1);
     const bool pa = maxNb > 128;
+    const int  pfx = kD ? pfxArg : 0;
     HcState s; s.src = src; s.pfx = pfx; s.w = w; s.d = d;
     hc_prime(s, level);
 
@@ -389,13 +395,13 @@ DEV int hc_compress_chain(const uint8_t* src, const int pfx, const int n, uint8_
 
     if (n < kMinLength) goto last_literals;                                                      // :1155
     while (ip <= mflimit) {
-        m1 = hc_find_wider(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, pa, false);              // :1159
+        m1 = hc_find_wider<kD>(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, pa, false);              // :1159
         if (m1.len < kMinMatch) { ip++; continue; }
         start0 = ip; m0 = m1;
 search2:
         if (ip + m1.len <= mflimit) {                                                            // :1167-1175
             start2 = ip + m1.len - 2;
-            m2 = hc_find_wider(s, start2, ip, matchlimit, m1.len, maxNb, pa, false);
+            m2 = hc_find_wider<kD>(s, start2, ip, matchlimit, m1.len, maxNb, pa, false);
             start2 += m2.back;
         } else { m2.len = 0; m2.off = 0; m2.back = 0; }
         if (m2.len <= m1.len) {                                                                  // :1177-1184
@@ -416,7 +422,7 @@ search3:
         }
         if (start2 + m2.len <= mflimit) {                                                        // :1212-1220
             start3 = start2 + m2.len - 3;
-            m3 = hc_find_wider(s, start3, start2, matchlimit, m2.len, maxNb, pa, false);
+            m3 = hc_find_wider<kD>(s, start3, start2, matchlimit, m2.len, maxNb, pa, false);
             start3 += m3.back;
         } else { m3.len = 0; m3.off = 0; m3.back = 0; }
         if (m3.len <= m2.len) {                                                                  // :1222-1240
@@ -492,10 +498,12 @@ DEV HcMatch mid_search_ctx(const HcDict& d, const uint8_t* ipp, uint32_t ipIndex
     return m;
 }
 
-DEV int hc_compress_mid(const uint8_t* src, const int pfx, const int n, uint8_t* __restrict__ dst, const int cap, HcWork w, const HcDict& d)
+template <bool kD>
+DEV int hc_compress_mid(const uint8_t* src, const int pfxArg, const int n, uint8_t* __restrict__ dst, const int cap, HcWork w, const HcDict& d)
 {
     if ((uint32_t)n > (uint32_t)kMaxInput) return 0;
     const bool limited = cap < compress_bound(n);
+    const int  pfx = kD ? pfxArg : 0;
     HcState s; s.src = src; s.pfx = pfx; s.w = w; s.d = d;
     hc_prime(s, 2);
     uint32_t* const h4t = w.hash;
@@ -537,7 +545,7 @@ DEV int hc_compress_mid(const uint8_t* src, const int pfx, const int n, uint8_t*
                 }
             } else ml = 0;
         }
-        if (!ml && d.mode == kHcCtx && ipIndex - kHcBase < 65535u - 8u) {                        // :652-665
+        if (kD && !ml && d.mode == kHcCtx && ipIndex - kHcBase < 65535u - 8u) {                        // :652-665
             const HcMatch dm = mid_search_ctx(d, src + ip, ipIndex, mlim);
             if (dm.len >= kMinMatch) { ml = dm.len; dist = (uint32_t)dm.off; }
         }
@@ -562,7 +570,8 @@ DEV int hc_compress_mid(const uint8_t* src, const int pfx, const int n, uint8_t*
 }
 
 // Level table rows 10..12 (lz4hc.c:92-106): {nbSearches, targetLength}; fullUpdate only at level 12 (:1406).
-DEV int hc_compress_opt(const uint8_t* src, const int pfx, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w, const HcDict& d)
+template <bool kD>
+DEV int hc_compress_opt(const uint8_t* src, const int pfxArg, const int n, uint8_t* __restrict__ dst, const int cap, const int level, HcWork w, const HcDict& d)
 {
     if ((uint32_t)n > (uint32_t)kMaxInput) return 0;                                             // :1388
     const bool limited = cap < compress_bound(n);                                                // :1505-1508
@@ -572,6 +581,7 @@ DEV int hc_compress_opt(const uint8_t* src, const int pfx, const int n, uint8_t*
     if (sufficient >= (size_t)kHcOptNum) sufficient = kHcOptNum - 1;                             // :1860
     HcOpt* const opt = w.opt;
 
+    const int pfx = kD ? pfxArg : 0;
     HcState s; s.src = src; s.pfx = pfx; s.w = w; s.d = d;
     hc_prime(s, level);
 
@@ -584,7 +594,7 @@ DEV int hc_compress_opt(const uint8_t* src, const int pfx, const int n, uint8_t*
     while (ip <= mflimit) {                                                                      // :1863
         const int llen = ip - anchor;
         int best_mlen, best_off, cur, last_match_pos = 0;
-        const HcMatch first = hc_find_longer(s, ip, matchlimit, kMinMatch - 1, nbSearches);
+        const HcMatch first = hc_find_longer<kD>(s, ip, matchlimit, kMinMatch - 1, nbSearches);
         if (first.len == 0) { ip++; continue; }
         if ((size_t)first.len > sufficient) {                                                    // :1871-1882
             if (hc_encode_seq(src, &ip, dst, &op, &anchor, first.len, first.off, limited, oend)) return 0;
@@ -610,8 +620,8 @@ DEV int hc_compress_opt(const uint8_t* src, const int pfx, const int n, uint8_t*
             } else {
                 if (opt[cur + 1].price <= opt[cur].price) continue;
             }
-            const HcMatch nm = fullUpdate ? hc_find_longer(s, curPos, matchlimit, kMinMatch - 1, nbSearches)
-                                          : hc_find_longer(s, curPos, matchlimit, last_match_pos - cur, nbSearches);
+            const HcMatch nm = fullUpdate ? hc_find_longer<kD>(s, curPos, matchlimit, kMinMatch - 1, nbSearches)
+                                          : hc_find_longer<kD>(s, curPos, matchlimit, last_match_pos - cur, nbSearches);
             if (!nm.len) continue;
             if ((size_t)nm.len > sufficient || nm.len + cur >= kHcOptNum) {                      // :1948-1956
                 best_mlen = nm.len; best_off = nm.off; last_match_pos = cur + 1; direct = true;
@@ -674,14 +684,19 @@ DEV int hc_compress(const uint8_t* blk, const int n, uint8_t* __restrict__ dst, 
     if (level > 12) level = 12;
     const int pfx = d.mode == kHcExt ? d.len : 0;
     const uint8_t* const src = blk - pfx;
-    if (level <= 2) return hc_compress_mid(src, pfx, n, dst, cap, w, d);
-    if (level <= 9) return hc_compress_chain(src, pfx, n, dst, cap, level, w, d);
-    return hc_compress_opt(src, pfx, n, dst, cap, level, w, d);
+    if (level <= 2) return hc_compress_mid<true>(src, pfx, n, dst, cap, w, d);
+    if (level <= 9) return hc_compress_chain<true>(src, pfx, n, dst, cap, level, w, d);
+    return hc_compress_opt<true>(src, pfx, n, dst, cap, level, w, d);
 }
-DEV int hc_compress(const uint8_t* blk, const int n, uint8_t* __restrict__ dst, const int cap, int level, HcWork w)
+// LZ4_compress_HC proper: an independent block, no dictionary (the hot path of BASELINE config 4)
+DEV int hc_compress(const uint8_t* __restrict__ blk, const int n, uint8_t* __restrict__ dst, const int cap, int level, HcWork w)
 {
+    if (level < 1) level = 9;
+    if (level > 12) level = 12;
     HcDict d; d.mode = kHcNone; d.len = 0; d.bytes = nullptr; d.hash = nullptr; d.chain = nullptr;
-    return hc_compress(blk, n, dst, cap, level, w, d);
+    if (level <= 2) return hc_compress_mid<false>(blk, 0, n, dst, cap, w, d);
+    if (level <= 9) return hc_compress_chain<false>(blk, 0, n, dst, cap, level, w, d);
+    return hc_compress_opt<false>(blk, 0, n, dst, cap, level, w, d);
 }
 
 // The tables a dictionary context carries (clz4.NewDictCtxHC, clz4.go:122-147 == LZ4_loadDictHC): `w` <- tables over dict[0, len).
