@@ -150,3 +150,28 @@ def test_gpu_linked_encode_in_many_chunks(orc, level, monkeypatch):
             r, c = orc.compress_linked(b, bsz, tail, orc.dict_ctx(user) if prev is None else None)
             assert g.tobytes() == _record(orc, r, c, b, True); prev = b
     e.dict_destroy(d); e.close()
+
+
+@pytest.mark.parametrize("kind", ["T", "M"])
+def test_gpu_linked_records_full_size_blocks(orc, eng, kind):
+    """BASELINE configs[4] at its real size: 4 MiB linked blocks + a 64 KiB dictionary; records == oracle stream emulation,
+    and the chain decodes back (the random parts of M are stored blocks, so the decode is checked on T only: the reference's
+    reader does not feed stored blocks into its window)."""
+    bsz = 4 << 20
+    user = synth.text(65536, seed=77)
+    data = synth.make(kind, 3 * bsz + 12345, bsz, seed=21)
+    blocks = [np.ascontiguousarray(data[o:o + bsz]) for o in range(0, data.size, bsz)]
+    dctx = orc.dict_ctx(user); d = eng.dict_create(np.ascontiguousarray(user))
+    got = eng.encode_records_ex(blocks, bsz, True, linked=True, d=d)
+    prev = None
+    for i, (b, g) in enumerate(zip(blocks, got)):
+        tail = None if prev is None else prev[-65536:].copy()
+        r, c = orc.compress_linked(b, bsz, tail, dctx if prev is None else None)
+        assert g.tobytes() == _record(orc, r, c, b, True), (kind, i); prev = b
+    if kind == "T":
+        window = np.zeros(65536, dtype=np.uint8); window[:] = user
+        res, st, outs, wl = eng.decode_records_ex([np.ascontiguousarray(g) for g in got], bsz, True, linked=True, window=window, window_len=65536)
+        assert not any(st)
+        for b, o in zip(blocks, outs):
+            assert np.array_equal(b, o)
+    eng.dict_destroy(d)
