@@ -1,10 +1,10 @@
 // plz4hip.hip -- gfx950 kernels + the C ABI declared in include/plz4hip.h.
 //
-// Launch shape: ONE 64-lane wavefront per LZ4 block, one wavefront per workgroup, persistent waves pulling
-// block indices from a device-side counter (every wave exits when the counter passes nBlocks).  The encoder
-// owns 16 KiB of LDS (liblz4's hash table, lz4.h:695-697): nine encoder waves per CU; the record decoder stages
-// each batch of output in 1.1 KiB of LDS and is bounded by its registers (24 waves per CU).  Independent blocks
-// never communicate.
+// Launch shape: ONE 64-lane wavefront per LZ4 block, persistent waves pulling block indices from a device-side
+// counter (every wave exits when the counter passes nBlocks).  An encoder wave owns 16 KiB of LDS (liblz4's hash
+// table, lz4.h:695-697): ten encoder waves per CU when a call fills the chip (one workgroup of ten independent waves
+// per CU, see ENC_WAVE_TABLE), one-wave workgroups otherwise; the record decoder stages each batch of output in
+// 1.1 KiB of LDS and is bounded by its registers (24 waves per CU).  Waves never communicate.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
