@@ -292,6 +292,30 @@ func (c *Ctx) DecodeRecordsEx(rec, dst [][]byte, bsz int, blockChecksum, linked 
 	return
 }
 
+// DecodeRecordsChains decodes several linked frames in one call: chain k = rec[chainFirst[k]:chainFirst[k+1]], one wavefront
+// each; windows holds the 64 KiB compress.DictT state of every chain back to back (len(chainFirst)-1 of them), windowLen
+// their lengths, both updated.  (No counterpart in the reference, which decodes a linked frame on one goroutine, rdr.go:339-341;
+// a server with many such frames hands them over together instead of one after the other.)
+func (c *Ctx) DecodeRecordsChains(chainFirst []int32, rec, dst [][]byte, bsz int, blockChecksum bool, windows []byte, windowLen []int32) (n []int, status []int, err error) {
+	r, o := newBatch(rec, false), newBatch(dst, true)
+	defer r.free()
+	defer o.free()
+	res := make([]C.int32_t, len(rec)+1)
+	st := make([]C.int32_t, len(rec)+1)
+	nChains := len(chainFirst) - 1
+	rc := C.plz4hip_decode_records_chains(c.p, C.int(nChains), (*C.int32_t)(unsafe.Pointer(&chainFirst[0])), (**C.void)(r.ptrs), &r.lens[0],
+		C.int(bsz), b2i(blockChecksum), unsafe.Pointer(&windows[0]), (*C.int32_t)(unsafe.Pointer(&windowLen[0])),
+		(**C.void)(o.ptrs), &res[0], &st[0])
+	if rc != C.PLZ4HIP_OK {
+		return nil, nil, c.engineErr(rc)
+	}
+	n, status = make([]int, len(rec)), make([]int, len(rec))
+	for i := range rec {
+		n[i], status[i] = int(res[i]), int(st[i])
+	}
+	return
+}
+
 func b2i(b bool) C.int {
 	if b {
 		return 1

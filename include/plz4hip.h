@@ -138,6 +138,15 @@ int plz4hip_encode_records_ex(plz4hip_ctx* ctx, int nBlocks, const void* const* 
 int plz4hip_decode_records_ex(plz4hip_ctx* ctx, int nBlocks, const void* const* rec, const int32_t* recLen,
                               int bsz, int blockChecksum, int linked, const plz4hip_dict* dict,
                               void* window, int* windowLen, void* const* dst, int32_t* result, int32_t* status);
+/* Linked decode of SEVERAL frames in one call.  The blocks of one linked frame are a serial chain ("replicas
+ * only"), chains of different frames share nothing: chain k = records [chainFirst[k], chainFirst[k+1]) (chainFirst[0] == 0,
+ * nChains + 1 entries), one wavefront each.  windows = nChains x 64 KiB, windowLen[nChains]: the compress.DictT state of every
+ * chain, in/out, exactly as `window` / `windowLen` of plz4hip_decode_records_ex(linked = 1); per-block result / status likewise
+ * (a chain stops at its first bad block, the other chains go on).  No counterpart in the reference: a server that decodes
+ * many linked frames (rdr.go:339-341 runs each one on a single goroutine) hands them over together. */
+int plz4hip_decode_records_chains(plz4hip_ctx* ctx, int nChains, const int32_t* chainFirst,
+                                  const void* const* rec, const int32_t* recLen, int bsz, int blockChecksum,
+                                  void* windows, int32_t* windowLen, void* const* dst, int32_t* result, int32_t* status);
 
 /* ---------------------------------------------------------------------------------------------------------
  * C. Device-resident pipeline (bench.py, GPU-to-GPU producers).  Every pointer below is a DEVICE pointer

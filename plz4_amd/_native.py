@@ -19,7 +19,7 @@ SYMBOLS = [
     "plz4hip_xxh32_batch", "plz4hip_encode_records", "plz4hip_decode_records", "plz4hip_dev_stage_stride",
     "plz4hip_dev_encode_records", "plz4hip_dev_compact_records", "plz4hip_dev_scatter_records",
     "plz4hip_dev_decode_records", "plz4hip_dev_compress", "plz4hip_dev_decompress",
-    "plz4hip_dev_resident_waves", "plz4hip_dict_create", "plz4hip_dict_destroy", "plz4hip_compress_batch_dict",
+    "plz4hip_dev_resident_waves", "plz4hip_dict_create", "plz4hip_dict_destroy", "plz4hip_compress_batch_dict", "plz4hip_decode_records_chains",
     "plz4hip_decompress_batch_dict", "plz4hip_encode_records_ex", "plz4hip_decode_records_ex",
 ]
 
@@ -96,6 +96,8 @@ def load():
     L.plz4hip_compress_batch_dict.argtypes = [vp, C.c_int, pp, i32p, pp, i32p, C.c_int, vp, i32p]
     L.plz4hip_decompress_batch_dict.restype = C.c_int
     L.plz4hip_decompress_batch_dict.argtypes = [vp, C.c_int, pp, i32p, pp, i32p, vp, i32p]
+    L.plz4hip_decode_records_chains.restype = C.c_int
+    L.plz4hip_decode_records_chains.argtypes = [vp, C.c_int, i32p, pp, i32p, C.c_int, C.c_int, vp, i32p, pp, i32p, i32p]
     L.plz4hip_encode_records_ex.restype = C.c_int
     L.plz4hip_encode_records_ex.argtypes = [vp, C.c_int, pp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, pp, i32p]
     L.plz4hip_decode_records_ex.restype = C.c_int
@@ -240,6 +242,29 @@ class Engine:
                                                    window.ctypes.data if window is not None else None, C.byref(wl),
                                                    _ptr_array(dsts), _i32p(res), _i32p(st)))
         return res, st, [x[:max(int(r), 0)] for x, r in zip(dsts, res)], wl.value
+
+    def decode_records_chains(self, chains, bsz, block_checksum, windows=None, window_lens=None):
+        """chains: list of lists of records (one linked frame each).  windows: uint8[nChains, 65536] (in/out) or None for empty
+        windows.  Returns (res, st, outs) per chain, and the window lengths."""
+        nch = len(chains)
+        first = np.zeros(nch + 1, dtype=np.int32)
+        for k, ch in enumerate(chains):
+            first[k + 1] = first[k] + len(ch)
+        recs = [r for ch in chains for r in ch]
+        n = len(recs); lens = _i32([r.size for r in recs])
+        dsts = [np.zeros(bsz + 8, dtype=np.uint8) for _ in range(n)]
+        res = np.zeros(max(n, 1), dtype=np.int32); st = np.zeros(max(n, 1), dtype=np.int32)
+        if windows is None:
+            windows = np.zeros((max(nch, 1), 65536), dtype=np.uint8)
+        wl = np.zeros(max(nch, 1), dtype=np.int32) if window_lens is None else np.ascontiguousarray(window_lens, dtype=np.int32)
+        self._chk(self.L.plz4hip_decode_records_chains(self.h, nch, _i32p(first), _ptr_array(recs) if n else None, _i32p(lens) if n else None,
+                                                       bsz, int(block_checksum), windows.ctypes.data, _i32p(wl),
+                                                       _ptr_array(dsts) if n else None, _i32p(res), _i32p(st)))
+        out = []
+        for k in range(nch):
+            a, b = int(first[k]), int(first[k + 1])
+            out.append((res[a:b].copy(), st[a:b].copy(), [d[:max(int(r), 0)] for d, r in zip(dsts[a:b], res[a:b])]))
+        return out, wl
 
     # ---- C. device-resident pipeline (raw device pointers; torch tensors supply .data_ptr())
     def dev_encode_records(self, src_ptr, src_bytes, bsz, block_checksum, stage_ptr, reclen_ptr, stream=0, level: int = 1):

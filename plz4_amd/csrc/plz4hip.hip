@@ -41,7 +41,8 @@ struct CodecArgs {
     const uint32_t* dictTable;                      // LZ4_loadDictSlow table of that dictionary
     int             linked;                         // encode: block i>0 is primed with the tail of block i-1
     const uint8_t*  prevTail;   int prevTailLen;    // linked: window of block 0 (-1: block 0 starts a frame)
-    uint8_t*        window;     int* windowLen;     // linked decode: the 64 KiB sliding dictionary (2 x 64 KiB ping-pong), in/out
+    uint8_t*        window;     int* windowLen;     // linked decode: the 64 KiB sliding dictionary (2 x 64 KiB ping-pong) per chain, in/out
+    int             nChains;    const int32_t* chainFirst;   // linked decode of several frames at once: chain c = records [chainFirst[c], chainFirst[c+1])
     // HC levels 2..12
     int             level;
     uint8_t*        hcWork;                         // gridDim.x x kHcWorkBytes
@@ -226,31 +227,37 @@ __global__ __launch_bounds__(64) void k_decode_rec_dict(CodecArgs a)
 __global__ __launch_bounds__(64) void k_decode_rec_linked(CodecArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t dl[kDecLdsBytes];
-    uint8_t* winA = a.window; uint8_t* winB = a.window + 65536;
-    int winLen = *a.windowLen;
-    bool dead = false;
-    for (int i = 0; i < a.nBlocks; ++i) {
-        int r = 0, st = PLZ4HIP_BLK_CORRUPT; bool stored = false;
-        if (!dead) decode_one_record(a, i, winA, winLen, &r, &st, &stored, dl);
-        if ((threadIdx.x & 63u) == 0) { a.result[i] = r; a.status[i] = st; }
-        if (st != PLZ4HIP_BLK_OK) { dead = true; continue; }             // first error ends the stream
-        if (stored) continue;
-        const uint8_t* out = a.dst + (int64_t)i * a.dstStride;
-        WAVE_FENCE();
-        if (r >= 65536) { wave_copy(winB, out + (r - 65536), 65536); winLen = 65536; }
-        else {
-            int keep = winLen;
-            if (winLen + r > 65536) keep = 65536 - r;
-            wave_copy(winB, winA + (winLen - keep), keep);
-            wave_copy(winB + keep, out, r);
-            winLen = keep + r;
+    // one wave per chain (frame); chains are independent of each other ("replicas"), the blocks of one chain are not
+    for (int ch = next_block(a.queue); ch < a.nChains; ch = next_block(a.queue)) {
+        const int first = a.chainFirst ? a.chainFirst[ch] : 0;
+        const int last  = a.chainFirst ? a.chainFirst[ch + 1] : a.nBlocks;
+        uint8_t* const win0 = a.window + (size_t)ch * 131072;
+        uint8_t* winA = win0; uint8_t* winB = win0 + 65536;
+        int winLen = a.windowLen[ch];
+        bool dead = false;
+        for (int i = first; i < last; ++i) {
+            int r = 0, st = PLZ4HIP_BLK_CORRUPT; bool stored = false;
+            if (!dead) decode_one_record(a, i, winA, winLen, &r, &st, &stored, dl);
+            if ((threadIdx.x & 63u) == 0) { a.result[i] = r; a.status[i] = st; }
+            if (st != PLZ4HIP_BLK_OK) { dead = true; continue; }             // first error ends the stream
+            if (stored) continue;
+            const uint8_t* out = a.dst + (int64_t)i * a.dstStride;
+            WAVE_FENCE();
+            if (r >= 65536) { wave_copy(winB, out + (r - 65536), 65536); winLen = 65536; }
+            else {
+                int keep = winLen;
+                if (winLen + r > 65536) keep = 65536 - r;
+                wave_copy(winB, winA + (winLen - keep), keep);
+                wave_copy(winB + keep, out, r);
+                winLen = keep + r;
+            }
+            WAVE_FENCE();
+            uint8_t* t = winA; winA = winB; winB = t;
         }
-        WAVE_FENCE();
-        uint8_t* t = winA; winA = winB; winB = t;
+        // leave the live window in the first half for the next call
+        if (winA != win0) { WAVE_FENCE(); wave_copy(win0, winA, winLen); }
+        if ((threadIdx.x & 63u) == 0) a.windowLen[ch] = winLen;
     }
-    // leave the live window in the first half for the next call
-    if (winA != a.window) { WAVE_FENCE(); wave_copy(a.window, winA, winLen); }
-    if ((threadIdx.x & 63u) == 0) *a.windowLen = winLen;
 }
 
 __global__ __launch_bounds__(64) void k_decode_raw_dict(CodecArgs a)
@@ -803,7 +810,8 @@ struct DictJob {                       // optional dictionary / linked parameter
     const plz4hip_dict* dict = nullptr;
     int   linked = 0;
     const void* prevTail = nullptr; int prevTailLen = -1;
-    uint8_t* window = nullptr; int* windowLen = nullptr;      // host buffers (64 KiB) for the linked decode chain
+    uint8_t* window = nullptr; int* windowLen = nullptr;      // host buffers (64 KiB, one length) per linked decode chain
+    int   nChains = 1; const int32_t* chainFirst = nullptr;   // several chains in one call (plz4hip_decode_records_chains)
     bool  any = false;
     int   level = 1;
 };
@@ -849,8 +857,12 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     // HC kernels index one shared workspace by workgroup: never two of them at once
     const int nSlots = hcMode ? 1 : (nChunks < plz4hip_ctx::kSlots ? nChunks : plz4hip_ctx::kSlots);
     const Staging st = plan(cb, maxIn, maxOut, gap);
-    const size_t offExtra = st.total;                          // [prevTail 64 KiB][window 2 x 64 KiB][windowLen]
-    const size_t slotBytes = st.total + (dictMode ? 3 * 65536 + 256 : 0);
+    // [prevTail 64 KiB][per chain: window 2 x 64 KiB][windowLen per chain][chainFirst]
+    const int    nCh = (dictMode && dj->window) ? dj->nChains : 1;
+    const size_t offExtra = st.total;
+    const size_t offWin = offExtra + 65536, offWinLen = offWin + (size_t)nCh * 131072, offFirst = offWinLen + round_up((size_t)nCh * 4, 256);
+    const size_t winBytes = (offFirst + round_up((size_t)(nCh + 1) * 4, 256)) - offWin;
+    const size_t slotBytes = st.total + (dictMode ? 65536 + winBytes : 0);
     for (int i = 0; i < nSlots; ++i) if (int rc = ensure_slot(c, i, slotBytes, slotBytes)) return rc;
 
     auto submit = [&](int k) -> int {
@@ -895,10 +907,12 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
                 a.prevTail = sl.d + offExtra; a.prevTailLen = ptLen;
             }
             if (dj->window) {
-                memcpy(sl.h + offExtra + 65536, dj->window, 65536);
-                memcpy(sl.h + offExtra + 3 * 65536, dj->windowLen, sizeof(int));
-                HIPCHK(c, hipMemcpyAsync(sl.d + offExtra + 65536, sl.h + offExtra + 65536, 2 * 65536 + 256, hipMemcpyHostToDevice, s));
-                a.window = sl.d + offExtra + 65536; a.windowLen = (int*)(sl.d + offExtra + 3 * 65536);
+                for (int ch = 0; ch < nCh; ++ch) memcpy(sl.h + offWin + (size_t)ch * 131072, dj->window + (size_t)ch * 65536, 65536);
+                memcpy(sl.h + offWinLen, dj->windowLen, (size_t)nCh * sizeof(int));
+                if (dj->chainFirst) memcpy(sl.h + offFirst, dj->chainFirst, (size_t)(nCh + 1) * sizeof(int32_t));
+                HIPCHK(c, hipMemcpyAsync(sl.d + offWin, sl.h + offWin, winBytes, hipMemcpyHostToDevice, s));
+                a.window = sl.d + offWin; a.windowLen = (int*)(sl.d + offWinLen);
+                a.nChains = nCh; a.chainFirst = dj->chainFirst ? (const int32_t*)(sl.d + offFirst) : nullptr;
             }
         }
         switch (mode) {
@@ -912,7 +926,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
                 else if (dictMode) ENC_LAUNCH(k_encode_rec_dict, nb, c, s, a);
                 else ENC_LAUNCH(k_encode_rec, nb, c, s, a); break;
         case 3: a.dstCap = nullptr;
-                if (dictMode && dj->linked) hipLaunchKernelGGL(k_decode_rec_linked, dim3(1), dim3(64), 0, s, a);
+                if (dictMode && dj->linked) hipLaunchKernelGGL(k_decode_rec_linked, dim3(grid_for(nCh, c->decWaves)), dim3(64), 0, s, a);
                 else if (dictMode) hipLaunchKernelGGL(k_decode_rec_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
                 else hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a); break;
         case 4: hipLaunchKernelGGL(k_xxh32, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s,
@@ -931,7 +945,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         // results, status, sizes and offsets now; the packed bytes once their total is known (retire)
         HIPCHK(c, hipMemcpyAsync(sl.h + st.offRes, sl.d + st.offRes, st.offIn - st.offRes, hipMemcpyDeviceToHost, s));
         if (dictMode && dj->window)
-            HIPCHK(c, hipMemcpyAsync(sl.h + offExtra + 65536, sl.d + offExtra + 65536, 2 * 65536 + 256, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(sl.h + offWin, sl.d + offWin, offFirst - offWin, hipMemcpyDeviceToHost, s));
         return PLZ4HIP_OK;
     };
     auto retire = [&](int k) -> int {
@@ -947,8 +961,8 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
             HIPCHK(c, hipStreamSynchronize(sl.s));
         }
         if (dictMode && dj->window) {
-            memcpy(dj->window, sl.h + offExtra + 65536, 65536);
-            memcpy(dj->windowLen, sl.h + offExtra + 3 * 65536, sizeof(int));
+            for (int ch = 0; ch < nCh; ++ch) memcpy(dj->window + (size_t)ch * 65536, sl.h + offWin + (size_t)ch * 131072, 65536);
+            memcpy(dj->windowLen, sl.h + offWinLen, (size_t)nCh * sizeof(int));
         }
         for (int i = 0; i < nb; ++i) { result[b0 + i] = hRes[i]; if (status) status[b0 + i] = hSt[i]; }
         if (mode != 4)
@@ -1089,6 +1103,25 @@ int plz4hip_decode_records_ex(plz4hip_ctx* c, int nBlocks, const void* const* re
     if (linked && (!window || !windowLen || *windowLen < 0 || *windowLen > 65536)) return fail(c, PLZ4HIP_E_ARG, "linked decode needs the 64 KiB window state");
     DictJob j; j.dict = dict; j.linked = linked; j.any = true;
     if (linked) { j.window = (uint8_t*)window; j.windowLen = windowLen; j.dict = nullptr; }
+    return host_codec(c, 3, nBlocks, rec, recLen, dst, nullptr, bsz, blockChecksum, result, status, &j);
+}
+
+int plz4hip_decode_records_chains(plz4hip_ctx* c, int nChains, const int32_t* chainFirst, const void* const* rec, const int32_t* recLen,
+                                  int bsz, int blockChecksum, void* windows, int32_t* windowLen,
+                                  void* const* dst, int32_t* result, int32_t* status)
+{
+    if (!c || nChains < 0 || bsz <= 0 || (nChains && (!chainFirst || !windows || !windowLen))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_decode_records_chains: bad argument");
+    if (nChains == 0) return PLZ4HIP_OK;
+    if (chainFirst[0] != 0) return fail(c, PLZ4HIP_E_ARG, "chainFirst[0] must be 0");
+    for (int k = 0; k < nChains; ++k) {
+        if (chainFirst[k + 1] < chainFirst[k]) return fail(c, PLZ4HIP_E_ARG, "chainFirst must not decrease");
+        if (windowLen[k] < 0 || windowLen[k] > 65536) return fail(c, PLZ4HIP_E_ARG, "window length out of range");
+    }
+    const int nBlocks = chainFirst[nChains];
+    if (nBlocks && (!rec || !recLen || !dst || !result || !status)) return fail(c, PLZ4HIP_E_ARG, "plz4hip_decode_records_chains: bad argument");
+    if (nBlocks == 0) return PLZ4HIP_OK;
+    for (int i = 0; i < nBlocks; ++i) if (recLen[i] < 4) return fail(c, PLZ4HIP_E_ARG, "record shorter than its size word");
+    DictJob j; j.linked = 1; j.any = true; j.window = (uint8_t*)windows; j.windowLen = windowLen; j.nChains = nChains; j.chainFirst = chainFirst;
     return host_codec(c, 3, nBlocks, rec, recLen, dst, nullptr, bsz, blockChecksum, result, status, &j);
 }
 

@@ -36,4 +36,19 @@ assert all(int(s) == 0 for s in st) and all(np.array_equal(o, s) for o, s in zip
 ratio = sum(r.size for r in recs) / (nblk * bsz)
 print("config 5 (linked + 64 KiB dictionary), level %d, %d x 4MiB, ratio %.4f: encode_records_ex %.0f MiB/s (host buffers, warm); "
       "decode chain of %d blocks %.0f MiB/s" % (level, nblk, ratio, nblk * 4 / (t1 - t0), ndec, ndec * 4 / (t3 - t2)))
+# many linked frames in one call: one wavefront per frame ("replicas only") -- F frames of 4 blocks each
+nf = max(nblk // 4, 1)
+frames = []
+enc4 = [np.ascontiguousarray(r) for r in eng.encode_records_ex(srcs[:4], bsz, True, linked=True, d=d)]
+for f in range(nf):
+    frames.append(enc4)
+wins = np.zeros((nf, 65536), dtype=np.uint8); wins[:] = dct[-65536:]
+wl = np.full(nf, 65536, dtype=np.int32)
+eng.decode_records_chains(frames[:8], bsz, True, windows=wins[:8].copy(), window_lens=wl[:8].copy())
+t4 = time.perf_counter()
+got, _ = eng.decode_records_chains(frames, bsz, True, windows=wins, window_lens=wl)
+t5 = time.perf_counter()
+assert all(not any(st) for _, st, _ in got) and all(np.array_equal(o, s) for o, s in zip(got[-1][2], srcs[:4]))
+print("config 5 decode, %d linked frames x 4 blocks x 4MiB in one call (plz4hip_decode_records_chains): %.0f MiB/s (host buffers, python wrapper included)"
+      % (nf, nf * 16 / (t5 - t4)))
 eng.dict_destroy(d); eng.close()

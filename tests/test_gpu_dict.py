@@ -175,3 +175,46 @@ def test_gpu_linked_records_full_size_blocks(orc, eng, kind):
         for b, o in zip(blocks, outs):
             assert np.array_equal(b, o)
     eng.dict_destroy(d)
+
+
+def test_gpu_linked_decode_of_several_frames_at_once(orc, eng):
+    """plz4hip_decode_records_chains: every linked frame is its own chain (one wavefront), chains share nothing.  The result of
+    each chain must be what plz4hip_decode_records_ex(linked=1) gives for it alone -- window state included -- and a corrupt
+    block stops its own chain only."""
+    bsz = 64 << 10
+    user = synth.text(70000, seed=3)
+    frames, windows, wlens = [], [], []
+    for f, (nblk, with_dict) in enumerate([(5, True), (1, False), (0, False), (7, False), (3, True)]):
+        data = synth.make("T" if f % 2 else "M", nblk * bsz - (777 if nblk else 0), bsz, seed=30 + f) if nblk else np.zeros(0, np.uint8)
+        blocks = [np.ascontiguousarray(data[o:o + bsz]) for o in range(0, data.size, bsz)]
+        d = eng.dict_create(np.ascontiguousarray(user)) if with_dict else None
+        recs = [np.ascontiguousarray(r) for r in eng.encode_records_ex(blocks, bsz, True, linked=True, d=d)] if blocks else []
+        if d is not None:
+            eng.dict_destroy(d)
+        w = np.zeros(65536, dtype=np.uint8); wl = 0
+        if with_dict:
+            wl = 65536; w[:] = user[-65536:]
+        frames.append((blocks, recs)); windows.append(w); wlens.append(wl)
+    bad = frames[3][1][2].copy(); bad[40] ^= 0x55                      # frame 3, block 2: checksum mismatch
+    frames[3] = (frames[3][0], frames[3][1][:2] + [bad] + frames[3][1][3:])
+    # each chain alone
+    alone = []
+    for (blocks, recs), w, wl in zip(frames, windows, wlens):
+        if not recs:
+            alone.append(([], [], [], wl, w.copy())); continue
+        wcopy = w.copy()
+        res, st, outs, wl2 = eng.decode_records_ex(recs, bsz, True, linked=True, window=wcopy, window_len=wl)
+        alone.append((list(res), list(st), outs, wl2, wcopy))
+    # all chains in one call
+    wall = np.stack(windows).copy()
+    got, wl_out = eng.decode_records_chains([recs for _, recs in frames], bsz, True, windows=wall, window_lens=np.array(wlens, dtype=np.int32))
+    for k, ((res, st, outs), (ares, ast, aouts, awl, aw)) in enumerate(zip(got, alone)):
+        assert list(res) == ares and list(st) == ast, k
+        for o, ao in zip(outs, aouts):
+            assert np.array_equal(o, ao), k
+        assert int(wl_out[k]) == awl and np.array_equal(wall[k][:awl], aw[:awl]), k
+    assert any(int(x) != 0 for x in got[3][1]) and not any(int(x) for x in got[0][1]) and not any(int(x) for x in got[4][1])
+    for k in (0, 1, 4):                                                # the frames without stored / bad blocks decode to their plaintext
+        if not any(r[3] & 0x80 for r in frames[k][1]):
+            for b, o in zip(frames[k][0], got[k][2]):
+                assert np.array_equal(b, o), k
