@@ -44,11 +44,18 @@ for f in range(nf):
     frames.append(enc4)
 wins = np.zeros((nf, 65536), dtype=np.uint8); wins[:] = dct[-65536:]
 wl = np.full(nf, 65536, dtype=np.int32)
-eng.decode_records_chains(frames[:8], bsz, True, windows=wins[:8].copy(), window_lens=wl[:8].copy())
-t4 = time.perf_counter()
-got, _ = eng.decode_records_chains(frames, bsz, True, windows=wins, window_lens=wl)
-t5 = time.perf_counter()
-assert all(not any(st) for _, st, _ in got) and all(np.array_equal(o, s) for o, s in zip(got[-1][2], srcs[:4]))
-print("config 5 decode, %d linked frames x 4 blocks x 4MiB in one call (plz4hip_decode_records_chains): %.0f MiB/s (host buffers, python wrapper included)"
+recs_all = [r for fr in frames for r in fr]
+nrec = len(recs_all)
+first = np.arange(0, nrec + 1, 4, dtype=np.int32)
+rlen = _i32([r.size for r in recs_all]); res = np.zeros(nrec, dtype=np.int32); st = np.zeros(nrec, dtype=np.int32)
+obuf = [np.zeros(bsz + 8, dtype=np.uint8) for _ in range(nrec)]                      # caller buffers ready before the clock starts
+rp2, op2 = _ptr_array(recs_all), _ptr_array(obuf)
+for rep in range(2):
+    w2 = wins.copy(); l2 = wl.copy()
+    t4 = time.perf_counter()
+    eng._chk(eng.L.plz4hip_decode_records_chains(eng.h, nf, _i32p(first), rp2, _i32p(rlen), bsz, 1, w2.ctypes.data, _i32p(l2), op2, _i32p(res), _i32p(st)))
+    t5 = time.perf_counter()
+assert not st.any() and all(np.array_equal(o[:bsz], s) for o, s in zip(obuf[-4:], srcs[:4]))
+print("config 5 decode, %d linked frames x 4 blocks x 4MiB in one call (plz4hip_decode_records_chains): %.0f MiB/s (host buffers, warm)"
       % (nf, nf * 16 / (t5 - t4)))
 eng.dict_destroy(d); eng.close()
