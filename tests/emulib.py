@@ -70,6 +70,11 @@ class Emu:
                                             _ptr(seg) if seg.size else nul, seg.size, mode))
         return r, dst[:max(r, 0)]
 
+    def set_old_dict(self, d: bool):
+        """True: every dictionary mode through the one-sequence-per-batch encoder (kept for the <= 4 KiB lookup mode), as a
+        cross-check of the external-segment mode of the full encoder."""
+        self.L.emu_set_old_dict(int(d))
+
     def set_descending(self, d: bool):
         self.L.emu_set_descending(int(d))
 

@@ -1,7 +1,8 @@
 """Fuzz for the level-1 encoder in its external-segment modes (linked blocks, dictionaries: BASELINE config 5), which run the
 grid batches since the segment is laid out right before the block: the device source (compiled for the CPU by tests/emu,
 ascending and descending lane order) against the oracle's stream emulation (pinned to the real liblz4 in
-tests/test_oracle_vs_ref.py) AND against the one-sequence-per-batch dictionary encoder kept for the <= 4 KiB lookup mode.
+tests/test_oracle_vs_ref.py).  (tests/test_emu_kernels.py::test_emu_both_dictionary_encoders_agree cross-checks it against the
+one-sequence-per-batch dictionary encoder kept for the <= 4 KiB lookup mode.)
 Not part of the test-suite (minutes); run from the repo root:  python tests/fuzz/fuzz_dict_emu.py [iters] [seed]"""
 import os
 import sys

@@ -184,6 +184,28 @@ def test_emu_encode_linked(orc, emu):
     assert a == b and np.array_equal(da, db)
 
 
+def test_emu_both_dictionary_encoders_agree(orc, emu):
+    """The external-segment mode of the full encoder (grid batches) and the one-sequence-per-batch dictionary encoder are two
+    restatements of the same reference path: same bytes, both lane orders, linked blocks and dictionary contexts."""
+    user = synth.text(40000, seed=5)
+    dctx = orc.dict_ctx(user); tab = _dict_table(dctx); dct = np.ascontiguousarray(user[-65536:])
+    data = corpus.structured(3 * 70000, 11)
+    blocks = [np.ascontiguousarray(data[o:o + 70000]) for o in range(0, data.size, 70000)]
+    try:
+        for desc in (False, True):
+            emu.set_descending(desc)
+            prev = None
+            for b in blocks:
+                cases = [(2, dct, tab)] if prev is None else [(1, np.ascontiguousarray(prev[-65536:]), None), (1, np.ascontiguousarray(prev[-9:]), None)]
+                for mode, seg, t in cases:
+                    emu.set_old_dict(False); r1, d1 = emu.compress_dict(b, b.size, seg, mode, t)
+                    emu.set_old_dict(True);  r2, d2 = emu.compress_dict(b, b.size, seg, mode, t)
+                    assert r1 == r2 and np.array_equal(d1, d2), (desc, mode, seg.size)
+                prev = b
+    finally:
+        emu.set_old_dict(False); emu.set_descending(False)
+
+
 def test_emu_decode_with_dictionary(orc, emu):
     dct_user = synth.text(70000, seed=99)
     dct = np.ascontiguousarray(dct_user[-65536:])
