@@ -162,18 +162,21 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
     while (mi >= lowest && attempts > 0) {
         int mlen = 0;
         attempts--;
+        // the chain link of this candidate is requested together with its bytes: one memory round trip per hop, not two
+        const uint32_t dn0 = s.w.chain[mi & 0xFFFFu];
         {
             const uint8_t* const mp = src + (mi - kHcBase);
+            const uint32_t m32 = ld32u(mp);       // requested with the 2-byte probe and the chain link, whether or not it gets looked at
             if (!kD || mi >= prefixIdx) {                                                        // within the prefix, :925-939
                 if (ld16u(iLow + longest - 1) == ld16u(mp - lookBack + longest - 1)) {
-                    if (ld32u(mp) == pattern) {
+                    if (m32 == pattern) {
                         const int back = lookBack ? hc_count_back(ip, mp, iLow, prefixPtr) : 0;
                         mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
                         mlen -= back;
                         if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
                     }
                 }
-            } else if (mi <= prefixIdx - 4u && ld32u(mp) == pattern) {                           // within the segment, :940-960
+            } else if (mi <= prefixIdx - 4u && m32 == pattern) {                                 // within the segment, :940-960
                 // count to the segment's end, then on into the prefix: one count over contiguous bytes
                 mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
                 const int back = lookBack ? hc_count_back(ip, mp, iLow, src) : 0;
@@ -186,8 +189,12 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
                 uint32_t distNext = 1;
                 const int end = longest - kMinMatch + 1;
                 int step = 1, accel = 1 << 4;
+                // the links of the first 64 positions of the match in one load (lane l: position l) instead of one memory
+                // round trip per position; a longer match goes on with single loads
+                LV(uint32_t, links);
+                { const uint32_t mi0 = mi; LANES({ links[I_] = (LANE < end) ? (uint32_t)s.w.chain[(mi0 + (uint32_t)LANE) & 0xFFFFu] : 0u; }) }
                 for (int p2 = 0; p2 < end; p2 += step) {
-                    const uint32_t cd = s.w.chain[(mi + (uint32_t)p2) & 0xFFFFu];
+                    const uint32_t cd = p2 < 64 ? RL(links, p2) : (uint32_t)s.w.chain[(mi + (uint32_t)p2) & 0xFFFFu];
                     step = (accel++ >> 4);
                     if (cd > distNext) { distNext = cd; chainPos = (uint32_t)p2; accel = 1 << 4; }
                 }
@@ -199,7 +206,7 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
             }
         }
         {
-            const uint32_t dn = s.w.chain[mi & 0xFFFFu];
+            const uint32_t dn = dn0;
             if (patternAnalysis && dn == 1 && chainPos == 0) {                                   // :989-1062
                 const uint32_t mci = mi - 1;
                 if (repeat == 0) {
@@ -244,7 +251,7 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
                 }
             }
         }
-        mi -= s.w.chain[(mi + chainPos) & 0xFFFFu];                                              // :1065
+        mi -= chainPos == 0 ? dn0 : s.w.chain[(mi + chainPos) & 0xFFFFu];                        // :1065
     }
     if (kD && s.d.mode == kHcCtx && attempts > 0 && within) {                                          // usingDictCtxHc, :1069-1098
         const uint32_t dictEnd = kHcBase + (uint32_t)s.d.len;        // the context's end index: its own indices start at 64 KiB
@@ -520,6 +527,8 @@ DEV int hc_compress_mid(const uint8_t* src, const int pfxArg, const int n, uint8
     if (n >= kMinLength) while (ip <= mflimit) {
         const uint32_t ipIndex = (uint32_t)ip + kHcBase;
         int ml = 0; uint32_t dist = 0;
+        const uint32_t h4 = mid_hash4(src + ip);
+        const uint32_t pos4 = h4t[h4];        // read together with the long table's entry (its slot is only written further down)
         {   // long match (:572-601)
             const uint32_t h8 = mid_hash8(src + ip);
             const uint32_t pos8 = h8t[h8];
@@ -528,8 +537,6 @@ DEV int hc_compress_mid(const uint8_t* src, const int pfxArg, const int n, uint8
             if (ml >= kMinMatch) dist = ipIndex - pos8; else ml = 0;
         }
         if (!ml) {   // short match, then one look at ip+1 for a longer one inside the prefix (:603-650)
-            const uint32_t h4 = mid_hash4(src + ip);
-            const uint32_t pos4 = h4t[h4];
             h4t[h4] = ipIndex;
             ml = mid_try(src, ip, ipIndex, pos4, prefixIdx, mlim, false);
             if (ml >= kMinMatch) {
