@@ -641,14 +641,30 @@ DEV int hc_compress_opt(const uint8_t* src, const int pfxArg, const int n, uint8
                     if (price < opt[pos].price) { opt[pos].mlen = 1; opt[pos].off = 0; opt[pos].litlen = baseLit + l; opt[pos].price = price; }
                 }
             }
-            for (int ml = kMinMatch; ml <= nm.len; ++ml) {                                       // :1974-2009
-                const int pos = cur + ml;
-                int price, ll;
-                if (opt[cur].mlen == 1) { ll = opt[cur].litlen; price = ((cur > ll) ? opt[cur - ll].price : 0) + hc_seq_price(ll, ml); }
-                else { ll = 0; price = opt[cur].price + hc_seq_price(0, ml); }
-                if (pos > last_match_pos + kHcTrailing || price <= opt[pos].price) {
-                    if (ml == nm.len && last_match_pos < pos) last_match_pos = pos;
-                    opt[pos].mlen = ml; opt[pos].off = nm.off; opt[pos].litlen = ll; opt[pos].price = price;
+            {   // :1974-2009.  The match lengths are independent of each other (each one reads and writes its own opt[cur + ml];
+                // last_match_pos only moves at the last one), so the lanes take one length each: one memory round trip for
+                // the whole loop instead of one per length.
+                const int ll = (opt[cur].mlen == 1) ? opt[cur].litlen : 0;
+                const int basePrice = (opt[cur].mlen == 1) ? ((cur > ll) ? opt[cur - ll].price : 0) : opt[cur].price;
+                const int lastOld = last_match_pos;
+                for (int ml0 = kMinMatch; ml0 <= nm.len; ml0 += 64) {
+                    LV(int, took);
+                    LANES({
+                        const int ml = ml0 + LANE;
+                        took[I_] = 0;
+                        if (ml <= nm.len) {
+                            const int pos = cur + ml;
+                            const int price = basePrice + hc_seq_price(ll, ml);
+                            if (pos > lastOld + kHcTrailing || price <= opt[pos].price) {
+                                took[I_] = 1;
+                                opt[pos].mlen = ml; opt[pos].off = nm.off; opt[pos].litlen = ll; opt[pos].price = price;
+                            }
+                        }
+                    })
+                    if (nm.len - ml0 < 64) {                                                     // the lane of the last length is in this chunk
+                        const int lastLane = nm.len - ml0;
+                        if (RL(took, lastLane) && lastOld < cur + nm.len) last_match_pos = cur + nm.len;
+                    }
                 }
             }
             for (int a = 1; a <= kHcTrailing; ++a) {                                             // :2011-2018
