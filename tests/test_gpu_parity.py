@@ -144,6 +144,29 @@ def test_gpu_decode_4m(orc, eng):
         assert int(r) == bsz and np.array_equal(o, s)
 
 
+def test_gpu_decode_corrupt_4m(orc, eng):
+    """Corruption deep inside a 4 MiB block: the LDS-staged vector decoder must stop where LZ4_decompress_safe stops, with the
+    same code (or accept what it accepts, with the same bytes)."""
+    bsz = 4 << 20
+    rng = np.random.default_rng(23)
+    comps, caps = [], []
+    for kind in ("T", "M"):
+        src = synth.make(kind, bsz, bsz)
+        c, comp = orc.compress_fast(src, orc.bound(bsz))
+        comp = np.ascontiguousarray(comp[:c])
+        for at in (c // 7, c // 3, c // 2, c - 70000, c - 300, c - 20):
+            for k in range(4):
+                bad = comp.copy()
+                i = min(at + int(rng.integers(0, 64)), c - 2)
+                if k == 0: bad[i] ^= 1 << int(rng.integers(0, 8))
+                elif k == 1: bad[i] = 0xFF
+                elif k == 2: bad[i:i + 2] = 0
+                else: bad = bad[:i]
+                comps.append(np.ascontiguousarray(bad)); caps.append(bsz + 8)
+    nbad = _check_decode(orc, eng, comps, caps)
+    assert nbad > 10
+
+
 def test_gpu_xxh32(orc, eng):
     rng = np.random.default_rng(3)
     bufs = [rng.integers(0, 256, size=n, dtype=np.uint8)
@@ -153,7 +176,7 @@ def test_gpu_xxh32(orc, eng):
         assert int(g) == orc.xxh32(b), b.size
 
 
-@pytest.mark.parametrize("bsz", [64 << 10, 4 << 20])
+@pytest.mark.parametrize("bsz", [64 << 10, 256 << 10, 1 << 20, 4 << 20])      # descriptor/index.go:5-38, idx 4..7
 @pytest.mark.parametrize("checksum", [False, True])
 def test_gpu_records(orc, eng, bsz, checksum):
     """blk.CompressToBlk / FrameReader+BlkT.Decompress on the device == oracle, incl. the stored-raw rule."""

@@ -86,7 +86,7 @@ def test_gpu_hc_golden_and_frame(orc):
     from plz4_amd import host
     from plz4_amd._native import Engine
     eng = Engine(0)
-    items = [(b, blk) for b, blk in _golden_blocks() if b["bsz"] <= (256 << 10)]
+    items = [(b, blk) for b, blk in _golden_blocks() if b["bsz"] <= (256 << 10)]      # 4 MiB: test_gpu_hc_config4_full_size
     for lvl in LEVELS:
         for bsz in sorted({b["bsz"] for b, _ in items}):
             sel = [(b, blk) for b, blk in items if b["bsz"] == bsz and b["level"] == lvl]
@@ -108,3 +108,30 @@ def test_gpu_hc_golden_and_frame(orc):
     n, out, err = host.Reader(e, f12).write_to()
     assert not err and out == payload
     e.close()
+
+
+@pytest.mark.gpu
+def test_gpu_hc_config4_full_size(ref, orc):
+    """BASELINE config 4 at its real size: 4 MiB blocks through the HC kernels.  Every committed 4 MiB digest (T blocks,
+    levels 2, 5, 9, 12 -- generated from the real LZ4_compress_HC by tests/golden/make_golden.py) and, at level 12, an M
+    block (text / random / zeros mix) against the reference run here; records decode back to the plaintext."""
+    from plz4_amd._native import Engine
+    eng = Engine(0)
+    bsz = 4 << 20
+    items = [(b, blk) for b, blk in _golden_blocks() if b["bsz"] == bsz]
+    assert {b["level"] for b, _ in items} >= {2, 5, 9, 12}
+    mblk = synth.make("M", bsz, bsz)
+    for lvl in sorted({b["level"] for b, _ in items}):
+        sel = [(b, blk) for b, blk in items if b["level"] == lvl]
+        srcs = [blk for _, blk in sel] + ([mblk] if lvl == 12 else [])
+        recs = eng.encode_records(srcs, bsz, True, level=lvl)
+        for (b, blk), rec in zip(sel, recs):
+            assert b["ret"] and not (rec[3] & 0x80) and rec.size - 8 == b["ret"], (lvl, b["index"], rec.size, b["ret"])
+            assert sha(rec[4:-4]) == b["comp_sha"], (b["kind"], b["index"], lvl)
+        if lvl == 12:
+            n, want = ref.compress_hc(mblk, bsz, 12)
+            assert n and recs[-1].size - 8 == n and np.array_equal(recs[-1][4:-4], want[:n])
+        res, st, outs = eng.decode_records([np.ascontiguousarray(r) for r in recs], bsz, True)
+        for s, r, k, o in zip(srcs, res, st, outs):
+            assert int(k) == 0 and int(r) == s.size and np.array_equal(o, s)
+    eng.close()
