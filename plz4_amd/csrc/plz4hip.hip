@@ -21,6 +21,7 @@ __device__ unsigned long long plz4_stats[24];
 #endif
 #include "lz4_device.inl"
 #include "lz4hc_device.inl"
+#include "lz4hc12_device.inl"
 
 namespace {
 
@@ -49,6 +50,13 @@ struct CodecArgs {
     const uint32_t* hcDictHash;                     // HC + dictionary: the dictionary context's tables for this level's strategy
     const uint16_t* hcDictChain;                    //   (clz4.NewDictCtxHC, clz4.go:122-147), built by k_hc_dict_prime
     int             hcEx;                           // HC call with a dictionary and/or linked blocks: inputs have 64 KiB of scratch in front
+    // level 12 in three phases (lz4hc12_device.inl): per-block chain and search results of the group [blk0, blk0 + nBlocks)
+    int             blk0;
+    uint16_t*       h12Chain;   int64_t h12ChainStride;      // entries per block (a multiple of 1024)
+    Hc12F*          h12F;       int64_t h12FStride;          // entries per block
+    uint8_t*        h12Ws;                                   // gridDim.x x kHc12WsGlobalBytes: the price table's overflow
+    int32_t*        h12Err;                                  // set when a kernel gives up (spin guard)
+    int             rawMode;                                 // parse kernel: 1 = raw LZ4 blocks (dstCap per block), 0 = frame records
 };
 
 __device__ __forceinline__ int next_block(uint32_t* q)
@@ -338,6 +346,178 @@ __global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
         if ((threadIdx.x & 63u) == 0) { st32u(rec, word); a.result[i] = len; }
     }
 }
+
+// ---------------------------------------------------------------------------------------------- HC level 12, three phases
+// Phase 1: the chain of every block of the group.  One wave per workgroup, the 128 KiB hash table in LDS (one block per CU).
+__global__ __launch_bounds__(64) void k_hc12_chain(CodecArgs a)
+{
+    __shared__ uint32_t tab[kHcHashEntries];
+    for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
+        const int i = a.blk0 + g;
+        const int n = block_len(a, i);
+        int nPad = (n + 1 + 1023) & ~1023;
+        if (nPad > a.h12ChainStride) nPad = (int)a.h12ChainStride;
+        hc12_build_chain(a.src + (int64_t)i * a.srcStride, n, a.h12Chain + (int64_t)g * a.h12ChainStride, nPad, tab);
+    }
+}
+
+// Phase 2: F(p) for the positions of every block of the group.  One 16-wave workgroup per block at a time; the chain of the
+// 64 KiB behind the positions in flight sits in LDS (a ring of 72 x 1024 entries fed from phase 1's array), the source bytes
+// come through L2.  Every lane runs one position (Hc12Lane), one chain step per loop trip; a lane that has finished takes the
+// next position from the block's queue in the same trip, so lanes never wait for the longest chain of their wave.
+struct Hc12Ctl { int qNext; int loaded; int skipUntil; int lock; int waveMin[16]; int cur; };
+
+__device__ __forceinline__ int h12_wave_min(int v)
+{
+    const int big = 0x7FFFFFFF;
+    int t;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x111, 0xF, 0xF, false); v = v < t ? v : t;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x112, 0xF, 0xF, false); v = v < t ? v : t;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x114, 0xF, 0xF, false); v = v < t ? v : t;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x118, 0xF, 0xF, false); v = v < t ? v : t;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x142, 0xA, 0xF, false); v = v < t ? v : t;
+    t = __builtin_amdgcn_update_dpp(big, v, 0x143, 0xC, 0xF, false); v = v < t ? v : t;
+    return __builtin_amdgcn_readlane(v, 63);
+}
+#define H12_LD(x)     (*(volatile int*)&(x))
+#define H12_ST(x, v)  (*(volatile int*)&(x) = (v))
+#define H12_ORDER()   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup")
+
+__global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t ring[kHc12RingEntries];
+    __shared__ Hc12Ctl ctl;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (;;) {
+        if (tid == 0) ctl.cur = (int)atomicAdd(a.queue, 1u);
+        __syncthreads();
+        const int g = ctl.cur;
+        if (g >= a.nBlocks) break;
+        const int i = a.blk0 + g;
+        const int n = block_len(a, i);
+        const uint8_t* const src = a.src + (int64_t)i * a.srcStride;
+        const uint16_t* const chain = a.h12Chain + (int64_t)g * a.h12ChainStride;
+        Hc12F* const F = a.h12F + (int64_t)g * a.h12FStride;
+        const int nPos = n - kMfLimit + 1 > 0 ? n - kMfLimit + 1 : 0;                // positions the parser can search
+        int nChain = (n + 1 + 1023) & ~1023;
+        if (nChain > a.h12ChainStride) nChain = (int)a.h12ChainStride;
+        if (tid == 0) { ctl.qNext = 0; ctl.loaded = 0; ctl.skipUntil = 0; ctl.lock = 0; }
+        if (tid < 16) ctl.waveMin[tid] = 0;
+        __syncthreads();
+
+        Hc12Ring ch; ch.r = ring;
+        Hc12Lane<Hc12Ring> L;
+        int st = 0, p = 0;                      // 0 idle, 1 searching p, 2 holds p and waits for its chain, 3 no positions left
+        unsigned idleTrips = 0;
+        for (;;) {
+            if (__builtin_amdgcn_ballot_w64(st == 0 || st == 2)) {
+                // (1) this wave's lower bound on the positions it holds or may still take: published BEFORE it takes new ones
+                const int q0 = H12_LD(ctl.qNext);
+                int m = h12_wave_min((st == 1 || st == 2) ? p : 0x7FFFFFFF);
+                if (q0 < m) m = q0;
+                if (lane == 0) H12_ST(ctl.waveMin[wv], m);
+                H12_ORDER();
+                // (2) keep the ring ahead of the queue: one wave at a time loads the next chunks.  The ring must still hold
+                // [p - 65535, p] of every position p in flight or yet to be taken: loaded - ring <= min(p) - 65535.
+                int loaded = H12_LD(ctl.loaded);
+                if (loaded < nChain && loaded < q0 + 2048) {
+                    int got = 0;
+                    if (lane == 0) got = atomicCAS(&ctl.lock, 0, 1) == 0;
+                    if (__builtin_amdgcn_readfirstlane(got)) {
+                        loaded = H12_LD(ctl.loaded);
+                        const int qn = H12_LD(ctl.qNext);               // first the queue head, then the waves' bounds
+                        H12_ORDER();
+                        int mn = h12_wave_min(lane < 16 ? H12_LD(ctl.waveMin[lane]) : 0x7FFFFFFF);
+                        if (qn < mn) mn = qn;
+                        while (loaded < nChain && loaded < qn + 4096 && loaded + kHc12RingChunk <= mn + (kHc12RingEntries - 65536)) {
+                            const uint4* gsrc = (const uint4*)(chain + loaded);
+                            uint4* ldst = (uint4*)(ring + ((((uint32_t)loaded >> 10) % (uint32_t)kHc12RingChunks) << 10));
+                            const uint4 v0 = gsrc[lane], v1 = gsrc[lane + 64];
+                            ldst[lane] = v0; ldst[lane + 64] = v1;
+                            loaded += kHc12RingChunk;
+                        }
+                        H12_ORDER();
+                        if (lane == 0) { H12_ST(ctl.loaded, loaded); H12_ORDER(); atomicExch(&ctl.lock, 0); }
+                    }
+                }
+                // (3) idle lanes take the next positions
+                const uint64_t idle = __builtin_amdgcn_ballot_w64(st == 0);
+                if (idle) {
+                    const int first = __builtin_ctzll(idle);
+                    int base = 0;
+                    if (lane == first) base = atomicAdd(&ctl.qNext, __builtin_popcountll(idle));
+                    base = __builtin_amdgcn_readlane(base, first);
+                    if (st == 0) { p = base + __builtin_popcountll(idle & ((1ull << lane) - 1)); st = p < nPos ? 2 : 3; }
+                }
+                // (4) a lane starts its position once the chain up to it is in the ring; positions inside a match longer than
+                // the parser's "sufficient" length are left to the parser (it jumps over them, lz4hc.c:1871-1882)
+                loaded = H12_LD(ctl.loaded);
+                const int skip = H12_LD(ctl.skipUntil);
+                if (st == 2) {
+                    if (p < skip) { Hc12F f; f.len = kHc12NotComputed; f.off = 0; F[p] = f; st = 0; }
+                    else if (p < loaded) { L.init(src, n, p, ch((uint32_t)p)); st = 1; }
+                }
+            }
+            if (!__builtin_amdgcn_ballot_w64(st != 3)) break;
+            if (st == 1) {
+                if (L.step(ch)) {
+                    const Hc12F f = L.result();
+                    F[p] = f;
+                    st = 0;
+                    if (f.len > kHc12Sufficient + 8) atomicMax(&ctl.skipUntil, p + f.len - kHc12Sufficient);
+                }
+            }
+            if (!__builtin_amdgcn_ballot_w64(st == 1)) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++idleTrips > (1u << 27)) { if (lane == 0) atomicExch(a.h12Err, 1); break; }      // never seen; bounds every spin
+            } else idleTrips = 0;
+        }
+        __syncthreads();
+    }
+}
+
+// Phase 3: the parser + writer + record framing, one wave per block.  The first kH12OptLds entries of the price table are in LDS.
+constexpr int kH12OptLds = 1024;
+__global__ __launch_bounds__(64) void k_hc12_parse(CodecArgs a)
+{
+    __shared__ int      oPrice[kH12OptLds];
+    __shared__ int      oLitlen[kH12OptLds];
+    __shared__ uint32_t oMloff[kH12OptLds];
+    __shared__ uint64_t seqs[64];
+    Hc12Ws w;
+    w.price = oPrice; w.litlen = oLitlen; w.mloff = oMloff; w.nl = kH12OptLds; w.seq = seqs;
+    {
+        uint8_t* gws = a.h12Ws + (size_t)blockIdx.x * kHc12WsGlobalBytes;
+        w.gprice = (int*)gws; w.glitlen = (int*)(gws + kHc12OptEntries * 4); w.gmloff = (uint32_t*)(gws + kHc12OptEntries * 8);
+    }
+    for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
+        const int i = a.blk0 + g;
+        const int      n   = block_len(a, i);
+        const uint8_t* s   = a.src + (int64_t)i * a.srcStride;
+        const Hc12F*   F   = a.h12F + (int64_t)g * a.h12FStride;
+        const uint16_t* ch = a.h12Chain + (int64_t)g * a.h12ChainStride;
+        if (a.rawMode) {
+            const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
+            const int r = hc12_parse(s, n, a.dst + (int64_t)i * a.dstStride, cap, F, ch, w);
+            if ((threadIdx.x & 63u) == 0) a.result[i] = r;
+            continue;
+        }
+        uint8_t* rec = a.dst + (int64_t)i * a.dstStride;
+        int c = hc12_parse(s, n, rec + 4, a.bsz, F, ch, w);              // capacity == bsz (blk.go:73); indie.go:80-88
+        uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
+        WAVE_FENCE();
+        if (c == 0) { wave_copy(rec + 4, s, n); c = n; word = 0x80000000u | ((uint32_t)n & 0x7FFFFFFFu); }
+        int len = c + 4;
+        if (a.blockChecksum) {
+            WAVE_FENCE();
+            const uint32_t x = wave_xxh32(rec + 4, c);
+            if ((threadIdx.x & 63u) == 0) st32u(rec + 4 + c, x);
+            len += 4;
+        }
+        if ((threadIdx.x & 63u) == 0) { st32u(rec, word); a.result[i] = len; }
+    }
+}
+
 // clz4.NewDictCtxHC (clz4.go:122-147): workgroup 0 builds the level-2 (lz4mid) tables of a dictionary, workgroup 1 the
 // hash-chain tables every other level shares.  tabs = 2 x kHcWorkBytes.
 __global__ __launch_bounds__(64) void k_hc_dict_prime(const uint8_t* dict, int len, uint8_t* tabs)
@@ -466,6 +646,11 @@ struct plz4hip_ctx {
     static constexpr int kSlots = 3;
     HostSlot     slot[kSlots];
     uint8_t*     d_hc = nullptr;   int hcWaves = 0;     // HC workspace, one slot per resident HC wave (allocated on first use)
+    // level 12 in three phases: chain + search results of one group of blocks, the parser's table overflow, an error flag
+    uint8_t*     d_h12 = nullptr;  size_t h12Bytes = 0;  int h12ParseWaves = 0;
+    // Both HC workspaces belong to one job at a time: the stream of the last HC job and an event recorded behind it; an HC
+    // job on another stream waits for that event on the device (no host block).
+    hipEvent_t   hcDone = nullptr; hipStream_t hcStream = nullptr; bool hcPending = false;
 };
 
 // == clz4.DictCtx (clz4.go:96-120): a private device copy of the last 64 KiB of the dictionary + the LZ4_loadDictSlow table.
@@ -478,7 +663,7 @@ struct plz4hip_dict {
 
 namespace {
 
-constexpr int kQueueSlots = 256;
+constexpr int kQueueSlots = 4096;         // work-queue counters, reused round-robin: far more than launches that can be in flight
 
 // LZ4_loadDict_internal(_ld_slow) on the host (lz4.c:1587-1646): the table a dictionary context carries.
 void build_dict_table_slow(const uint8_t* p, int n, uint32_t* tab)
@@ -580,6 +765,95 @@ int ensure_hc(plz4hip_ctx* c)
     return PLZ4HIP_OK;
 }
 
+// ---- HC jobs and their workspaces.  hc_enter: called before an HC job is enqueued on `s` -- if the previous HC job went to a
+// different stream, `s` waits for it on the device.  hc_leave: marks the end of the job on `s`.
+int hc_enter(plz4hip_ctx* c, hipStream_t s)
+{
+    if (c->hcPending && c->hcStream != s) HIPCHK(c, hipStreamWaitEvent(s, c->hcDone, 0));
+    return PLZ4HIP_OK;
+}
+int hc_leave(plz4hip_ctx* c, hipStream_t s)
+{
+    if (!c->hcDone) HIPCHK(c, hipEventCreateWithFlags(&c->hcDone, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->hcDone, s));
+    c->hcPending = true; c->hcStream = s;
+    return PLZ4HIP_OK;
+}
+
+// Level 12 on independent blocks without dictionary runs in three phases per group of blocks (lz4hc12_device.inl):
+// chain -> search results -> parser.  Per block the group workspace holds the chain (2 B per position) and F (8 B per
+// position); the group size follows from the memory set aside (PLZ4HIP_HC12_GROUP overrides, for tests).
+struct H12Plan { int64_t chainStride, fStride; size_t perBlock; int group; size_t offF, offWs, offErr, total; };
+int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
+{
+    pl->chainStride = (int64_t)round_up((size_t)maxLen + 1, 1024);
+    pl->fStride = (int64_t)round_up((size_t)(maxLen > 11 ? maxLen - 11 : 1), 64);
+    pl->perBlock = (size_t)pl->chainStride * 2 + (size_t)pl->fStride * 8;
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
+    size_t budget = (freeB + c->h12Bytes) / 4;
+    if (budget > ((size_t)40 << 30)) budget = (size_t)40 << 30;
+    int64_t grp = (int64_t)(budget / pl->perBlock);
+    if (const char* v = getenv("PLZ4HIP_HC12_GROUP")) { const int gv = atoi(v); if (gv >= 1) grp = gv; }
+    if (grp < 1) grp = 1;
+    if (grp > nBlocks) grp = nBlocks;
+    pl->group = (int)grp;
+    if (!c->h12ParseWaves) {
+        int per = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc12_parse, 64, 0) != hipSuccess || per < 1) per = 8;
+        c->h12ParseWaves = c->cus * per;
+    }
+    pl->offF = round_up((size_t)pl->group * (size_t)pl->chainStride * 2, 256);
+    pl->offWs = pl->offF + round_up((size_t)pl->group * (size_t)pl->fStride * 8, 256);
+    pl->offErr = pl->offWs + round_up((size_t)c->h12ParseWaves * kHc12WsGlobalBytes, 256);
+    pl->total = pl->offErr + 256;
+    if (pl->total > c->h12Bytes) {
+        if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));          // nothing may still use the old workspace
+        if (c->d_h12) hipFree(c->d_h12);
+        c->d_h12 = nullptr; c->h12Bytes = 0;
+        if (hipMalloc((void**)&c->d_h12, pl->total) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "level-12 workspace");
+        c->h12Bytes = pl->total;
+    }
+    return PLZ4HIP_OK;
+}
+
+bool use_h12(const CodecArgs& a) { return a.level >= 12 && !a.hcEx && getenv("PLZ4HIP_HC12_OFF") == nullptr; }
+
+// Enqueue one HC call of nb blocks (a: everything but queue / workspace filled in) on s.  rawMode: LZ4 blocks, else records.
+int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode)
+{
+    if (int rc = hc_enter(c, s)) return rc;
+    hipError_t e;
+    if (use_h12(a)) {
+        H12Plan pl;
+        if (int rc = plan_h12(c, nb, maxLen, &pl)) return rc;
+        a.h12Chain = (uint16_t*)c->d_h12; a.h12ChainStride = pl.chainStride;
+        a.h12F = (Hc12F*)(c->d_h12 + pl.offF); a.h12FStride = pl.fStride;
+        a.h12Ws = c->d_h12 + pl.offWs; a.h12Err = (int32_t*)(c->d_h12 + pl.offErr);
+        a.rawMode = rawMode;
+        HIPCHK(c, hipMemsetAsync(a.h12Err, 0, 4, s));
+        for (int g0 = 0; g0 < nb; g0 += pl.group) {
+            const int ng = nb - g0 < pl.group ? nb - g0 : pl.group;
+            a.blk0 = g0; a.nBlocks = ng;
+            a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+            hipLaunchKernelGGL(k_hc12_chain, dim3(grid_for(ng, c->cus)), dim3(64), 0, s, a);
+            a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+            hipLaunchKernelGGL(k_hc12_search, dim3(grid_for(ng, c->cus)), dim3(1024), 0, s, a);
+            a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+            hipLaunchKernelGGL(k_hc12_parse, dim3(grid_for(ng, c->h12ParseWaves)), dim3(64), 0, s, a);
+            HIPCHK(c, hipGetLastError());
+        }
+    } else {
+        if (int rc = ensure_hc(c)) return rc;
+        a.hcWork = c->d_hc; a.nBlocks = nb;
+        a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+        if (rawMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
+        else         hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
+        HIPCHK(c, hipGetLastError());
+    }
+    return hc_leave(c, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -653,6 +927,8 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
         if (sl.d) hipFree(sl.d);
     }
     if (c->d_hc) hipFree(c->d_hc);
+    if (c->d_h12) hipFree(c->d_h12);
+    if (c->hcDone) hipEventDestroy(c->hcDone);
     delete c;
 }
 
@@ -710,16 +986,16 @@ int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes
     std::lock_guard<std::mutex> g(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
     CodecArgs a{};
     a.src = (const uint8_t*)src; a.srcStride = bsz; a.srcBytes = srcBytes; a.bsz = bsz;
     a.dst = (uint8_t*)stage; a.dstStride = plz4hip_dev_stage_stride(bsz);
-    a.result = recLen; a.queue = q; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
+    a.result = recLen; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
+    a.dictLen = -1; a.prevTailLen = -1;
     if (is_hc_level(level)) {
-        if (int rc = ensure_hc(c)) return rc;
-        a.level = level; a.hcWork = c->d_hc;
-        hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nBlocks, c->hcWaves)), dim3(64), 0, s, a);
+        a.level = level;
+        return launch_hc(c, s, a, nBlocks, bsz, 0);
     } else {
+        hipError_t e; a.queue = next_queue(c, s, &e); HIPCHK(c, e);
         ENC_LAUNCH(k_encode_rec, nBlocks, c, s, a);
     }
     HIPCHK(c, hipGetLastError());
@@ -841,7 +1117,6 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     // previous block's source tail, which the caller's buffers hold: it is cut into chunks like any other call, the first
     // block of a later chunk getting the tail of the block before it as its prevTail.
     const bool chained = dictMode && dj->linked && mode == 3;
-    if (hcMode) { if (int rc = ensure_hc(c)) return rc; }
     if (dictMode && dj->prevTail && dj->prevTailLen > 65536) return fail(c, PLZ4HIP_E_ARG, "prevTail longer than 64 KiB");
 
     size_t kChunkBytes = (size_t)6 << 30;      // x kSlots in flight: enough blocks for every encoder wave slot at 4 MiB blocks
@@ -885,7 +1160,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         a.result = (int32_t*)(sl.d + st.offRes); a.status = (int32_t*)(sl.d + st.offSt);
         a.queue = q; a.nBlocks = nb; a.bsz = bsz; a.blockChecksum = blockChecksum; a.dstCapAll = bsz + 8;
         a.dictLen = -1; a.prevTailLen = -1;
-        if (hcMode) { a.level = dj->level; a.hcWork = c->d_hc; }
+        if (hcMode) a.level = dj->level;
         if (dictMode) {
             if (dj->dict) { a.dict = dj->dict->d_bytes; a.dictLen = dj->dict->len; a.dictTable = dj->dict->d_table; }
             if (hcMode) {
@@ -916,13 +1191,13 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
             }
         }
         switch (mode) {
-        case 0: if (hcMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
+        case 0: if (hcMode) { if (int rc = launch_hc(c, s, a, nb, maxIn, 1)) return rc; }
                 else if (dictMode) ENC_LAUNCH(k_encode_raw_dict, nb, c, s, a);
                 else ENC_LAUNCH(k_encode_raw, nb, c, s, a); break;
         case 1: if (dictMode) hipLaunchKernelGGL(k_decode_raw_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
                 else hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a); break;
         case 2: a.dstCap = nullptr;
-                if (hcMode) hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
+                if (hcMode) { if (int rc = launch_hc(c, s, a, nb, maxIn, 0)) return rc; }
                 else if (dictMode) ENC_LAUNCH(k_encode_rec_dict, nb, c, s, a);
                 else ENC_LAUNCH(k_encode_rec, nb, c, s, a); break;
         case 3: a.dstCap = nullptr;

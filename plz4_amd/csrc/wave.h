@@ -22,6 +22,7 @@
 // ---------------------------------------------------------------- CPU lane emulation (tests only)
 #include <string.h>
 #define DEV            static inline
+#define DEVM           inline                           /* member functions */
 #define LV(T, x)       T x[64]
 #define I_             lane_
 #define LANE           lane_
@@ -48,6 +49,7 @@ static inline int plz4_emu_step()  { return plz4_emu_descending ? -1 : 1; }
 // ---------------------------------------------------------------- gfx950
 #include <hip/hip_runtime.h>
 #define DEV            __device__ __forceinline__
+#define DEVM           __device__ __forceinline__
 #define LV(T, x)       T x[1]
 #define I_             0
 #define LANE           ((int)(threadIdx.x & 63u))

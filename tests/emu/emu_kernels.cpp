@@ -113,3 +113,38 @@ int emu_decode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, cons
 }
 
 }
+
+// ---- HC level 12 in its three device phases (lz4hc12_device.inl), back to back on the CPU.
+// ncEvery > 0: every ncEvery-th position is left to the parser's own search (the path for positions the search phase skips);
+// nl: entries of the price table kept in "LDS" (small values exercise the global part).
+#include "../../plz4_amd/csrc/lz4hc12_device.inl"
+extern "C" int emu_compress_hc12(const uint8_t* src, int n, uint8_t* dst, int cap, int ncEvery, int nl)
+{
+    using namespace plz4;
+    const int nPos = n - kMfLimit + 1 > 0 ? n - kMfLimit + 1 : 0;
+    const int nPad = ((n > 0 ? n : 0) + 1 + 1023) / 1024 * 1024;
+    uint16_t* chain = (uint16_t*)malloc((size_t)nPad * 2);
+    uint32_t* tab = (uint32_t*)malloc((size_t)kHcHashEntries * 4);
+    uint8_t* padded = (uint8_t*)calloc((size_t)(n > 0 ? n : 0) + 64, 1);
+    if (n > 0) memcpy(padded, src, (size_t)n);
+    hc12_build_chain(padded, n, chain, nPad, tab);
+    Hc12F* F = (Hc12F*)malloc(sizeof(Hc12F) * (size_t)(nPos + 1));
+    Hc12Flat ch; ch.c = chain;
+    int skipUntil = 0;                  // as the search kernel: positions inside a match longer than the parser's "sufficient" are left out
+    for (int p = 0; p < nPos; ++p) {
+        if ((ncEvery > 0 && p % ncEvery == ncEvery - 1) || p < skipUntil) { F[p].len = kHc12NotComputed; F[p].off = 0; continue; }
+        Hc12Lane<Hc12Flat> L; L.init(padded, n, p, ch((uint32_t)p));
+        while (!L.step(ch)) {}
+        F[p] = L.result();
+        if (F[p].len > kHc12Sufficient + 8 && p + F[p].len - kHc12Sufficient > skipUntil) skipUntil = p + F[p].len - kHc12Sufficient;
+    }
+    Hc12Ws w;
+    w.nl = nl;
+    w.price = (int*)malloc(4 * (size_t)nl); w.litlen = (int*)malloc(4 * (size_t)nl); w.mloff = (uint32_t*)malloc(4 * (size_t)nl);
+    w.gprice = (int*)malloc(4 * kHc12OptEntries); w.glitlen = (int*)malloc(4 * kHc12OptEntries); w.gmloff = (uint32_t*)malloc(4 * kHc12OptEntries);
+    uint64_t seq[64]; w.seq = seq;
+    const int r = hc12_parse(padded, n, dst, cap, F, chain, w);
+    free(w.price); free(w.litlen); free(w.mloff); free(w.gprice); free(w.glitlen); free(w.gmloff);
+    free(F); free(padded); free(tab); free(chain);
+    return r;
+}

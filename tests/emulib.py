@@ -12,7 +12,7 @@ from orclib import ROOT, _ptr, u8p
 
 EMU_SRC = os.path.join(ROOT, "tests", "emu", "emu_kernels.cpp")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "_build", "libemu.so")
-DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "lz4hc_device.inl", "wave.h")]
+DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "lz4hc_device.inl", "lz4hc12_device.inl", "wave.h")]
 
 
 def build_emu():
@@ -90,3 +90,11 @@ class Emu:
 
     def xxh32(self, a: np.ndarray) -> int:
         return int(self.L.emu_xxh32(_ptr(a) if a.size else C.cast(None, u8p), a.size))
+
+    def compress_hc12(self, src, cap, nc_every=0, nl=1024):
+        """Level 12 through the three device phases of lz4hc12_device.inl (chain, per-position search, parser)."""
+        self.L.emu_compress_hc12.restype = C.c_int
+        self.L.emu_compress_hc12.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+        dst = np.empty(max(cap, 1) + 64, dtype=np.uint8)
+        r = int(self.L.emu_compress_hc12(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, nc_every, nl))
+        return r, dst[:max(r, 0)]

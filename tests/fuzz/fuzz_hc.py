@@ -46,6 +46,13 @@ def main(iters=400, seed=7):
                 if a != b or not np.array_equal(da, db):
                     bad += 1
                     print("MISMATCH", it, kind, n, lvl, cap, a, b)
+                if lvl == 12:                            # the three-phase level-12 path (lz4hc12_device.inl): chain, per-position search, parser
+                    for nc, nl in ((0, 1024), (5, 48)):  # nc: positions left to the parser's own search; nl: price-table entries in "LDS"
+                        b, db = emu.compress_hc12(src, cap, nc, nl)
+                        tot += 1
+                        if a != b or not np.array_equal(da, db):
+                            bad += 1
+                            print("MISMATCH hc12", it, kind, n, cap, nc, nl, a, b)
     print("total", tot, "bad", bad)
     return bad
 
