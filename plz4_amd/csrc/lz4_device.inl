@@ -236,10 +236,12 @@ DEV int win_bck(const Win24& p, const Win24& c)
 #if defined(PLZ4_EMU)
 static inline uint32_t lds_max_rtn(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 static inline void     lds_min(uint32_t* p, uint32_t v)     { if (v < *p) *p = v; }
+static inline uint32_t lds_add_rtn(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 static inline void     lds_max(uint32_t* p, uint32_t v)     { if (v > *p) *p = v; }
 #else
 __device__ __forceinline__ uint32_t lds_max_rtn(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 __device__ __forceinline__ void     lds_min(uint32_t* p, uint32_t v)     { atomicMin(p, v); }
+__device__ __forceinline__ uint32_t lds_add_rtn(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ void     lds_max(uint32_t* p, uint32_t v)     { atomicMax(p, v); }
 #endif
 

@@ -9,11 +9,14 @@
 // Two facts make that parallel without changing one decision:
 //   (1) when position p is searched, EVERY position below p has been inserted (LZ4HC_Insert runs up to p, :914), whatever the
 //       parser did before -- so the chain is a function of the data alone: chain[q] = distance from q to the previous
-//       position with the same hash.  It is built for the whole block up front (hc12_build_chain), 64 positions per step.
+//       position with the same hash.  It is built for the whole block up front (hc12_build_lists), 64 positions per step --
+//       and not as a linked list only: the positions of every hash are also laid out as one ascending run (`list`, with
+//       rank[q] = where q sits in it), so that "the next candidates of this chain" are CONSECUTIVE entries a lane fetches
+//       eight at a time, instead of one dependent memory access per candidate.
 //   (2) level 12 always searches with the same parameters (minLen 3, forward only, :1936), so the search result of a position
 //       is a function of the data alone as well: F(p) = (length, offset).  It is computed for every position the parser may
-//       ask for, one position per LANE (Hc12Lane: one chain step per call, so that a kernel can refill finished lanes from a
-//       queue), ahead of the parser.
+//       ask for, one position per LANE (Hc12Walk), ahead of the parser; the 64 KiB of source behind the positions in flight
+//       sit in LDS, so the 2-byte / 4-byte tests of a candidate (95 % of all candidates end there) never leave the CU.
 //   The price DP stays serial per block but touches no match finder any more (hc12_parse): it reads F, scans the skip test
 //   (:1929-1934) for 64 positions at once, updates the prices of a match's lengths one length per lane, and hands the chosen
 //   sequences to a writer that lays out 64 sequences at a time.
@@ -33,67 +36,83 @@ enum : int { kHc12Sufficient = 4095,           // level 12: sufficient_len 4096,
              kHc12OptEntries = kHcOptNum + kHcTrailing + 1 };
 struct Hc12F { int32_t len; int32_t off; };    // LZ4HC_FindLongerMatch's answer for one position (len 0: none)
 
-// ------------------------------------------------------------------------------------------ phase 1: the chain
+// ------------------------------------------------------------------------------------------ phase 1: chains and lists
 // chain[q] (uint16): distance from q to the previous position with the same LZ4HC hash (lz4hc.c:120-122), 1..65535;
 // 0 = none within 65535.  liblz4's table holds min(distance, 65535) instead (:793-796); what differs is only that a head
 // candidate exactly 65535 back (valid, :913-916 read the hash table's full index) can be told from one further back.
 // hc12_raw gives liblz4's value back for the places that compare or subtract chain values.
+// list: the positions of hash 0 in ascending order, then those of hash 1, ...; offsets[h] = where hash h starts (a histogram
+// + prefix sum, made before); an entry carries kHc12First when it is the first position of its hash.  rank[q] = index of q
+// in list.  The chain walk "q, q - chain[q], ..." is list[rank[q]], list[rank[q] - 1], ... down to the entry with kHc12First.
 DEV uint32_t hc12_raw(uint32_t d) { return d ? d : 65535u; }
+static constexpr uint32_t kHc12First = 0x80000000u;
+DEV uint32_t hc12_hash(uint32_t v) { return (v * 2654435761u) >> 17; }
 
-// One wave, `tab` = 32768 x uint32 of LDS (128 KiB): last position + 1 per hash.  One atomic max per lane commits the lane's
-// position and returns the previous holder; same-slot lanes are expected to resolve in ascending lane order, any other order
-// shows up as a returned position >= the lane's own and is put right in place.  chain[0, nPad) is written (nPad % 64 == 0).
-DEV void hc12_build_chain(const uint8_t* __restrict__ src, const int n, uint16_t* __restrict__ chain, const int nPad, uint32_t* tab)
+// One wave.  Two passes over the block, one per half of the hash range, so that the two LDS tables (last position + 1 and
+// list cursor per hash: 2 x 64 KiB) fit.  Per lane one atomic max (commits the position, returns the previous holder) and one
+// atomic add (takes the list slot); same-slot lanes are expected to resolve in ascending lane order, any other order is
+// detected and put right in place.  chain[0, nPad) is written (nPad % 64 == 0), rank / list for positions below n - 3.
+DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const uint32_t* __restrict__ offsets,
+                          uint16_t* __restrict__ chain, uint32_t* __restrict__ rank, uint32_t* __restrict__ list, const int nPad,
+                          uint32_t* lastT, uint32_t* curT)
 {
-    LANES({ for (int i = LANE; i < kHcHashEntries; i += 64) tab[i] = 0u; })
-    LDS_FENCE();
     const int nIns = n >= 4 ? n - 3 : 0;                       // positions with 4 bytes to hash
-    for (int base = 0; base < nPad; base += 64) {
-        LV(uint32_t, h); LV(uint32_t, prev); LV(int, act);
-        LANES({
-            const int p = base + LANE;
-            act[I_] = p < nIns; h[I_] = 0; prev[I_] = 0;
-            if (act[I_]) {
-                h[I_] = (ld32u(src + p) * 2654435761u) >> 17;
-                prev[I_] = lds_max_rtn(&tab[h[I_]], (uint32_t)p + 1u);
-            }
-        })
+    for (int half = 0; half < 2; ++half) {
+        LANES({ for (int i = LANE; i < kHcHashEntries / 2; i += 64) { lastT[i] = 0u; curT[i] = offsets[half * (kHcHashEntries / 2) + i]; } })
         LDS_FENCE();
-        if (BALLOT(act[I_] && prev[I_] > (uint32_t)(base + LANE))) {
-            // some other resolution order: a slot's pre-batch value is the smallest value its lanes got back; every lane
-            // takes the nearest lower lane of its slot, or that pre-batch value
-            LV(uint32_t, gmin); LV(uint32_t, near);
-            LANES({ gmin[I_] = prev[I_]; near[I_] = 0; })
-            for (int l = 0; l < 64; ++l) {
-                const uint32_t hl = RL(h, l), pl = RL(prev, l); const int al = RL(act, l);
-                LANES({
-                    if (al && act[I_] && h[I_] == hl) {
-                        if (pl < gmin[I_]) gmin[I_] = pl;
-                        if (l < LANE) near[I_] = (uint32_t)(base + l) + 1u;
+        for (int base = 0; base < nPad; base += 64) {
+            LV(uint32_t, h); LV(uint32_t, prev); LV(uint32_t, slot); LV(int, act);
+            LANES({
+                const int p = base + LANE;
+                act[I_] = 0; h[I_] = 0; prev[I_] = 0; slot[I_] = 0;
+                if (p < nIns) {
+                    const uint32_t hv = hc12_hash(ld32u(src + p));
+                    if ((int)(hv >> 14) == half) {
+                        act[I_] = 1; h[I_] = hv & 16383u;
+                        prev[I_] = lds_max_rtn(&lastT[h[I_]], (uint32_t)p + 1u);
+                        slot[I_] = lds_add_rtn(&curT[h[I_]], 1u);
                     }
-                })
+                }
+            })
+            LDS_FENCE();
+            {   // in lane order, a lane whose predecessor is in this batch sits right behind it in the list
+                LV(uint32_t, ps);
+                LANES({ ps[I_] = SHFL(slot, (prev[I_] > (uint32_t)base) ? (int)(prev[I_] - 1u - (uint32_t)base) : LANE); })
+                if (BALLOT(act[I_] && (prev[I_] > (uint32_t)(base + LANE) || (prev[I_] > (uint32_t)base && slot[I_] != ps[I_] + 1u)))) {
+                    // some other resolution order: a hash's pre-batch values are the smallest its lanes got back
+                    LV(uint32_t, gmin); LV(uint32_t, smin); LV(uint32_t, near); LV(uint32_t, idx);
+                    LANES({ gmin[I_] = prev[I_]; smin[I_] = slot[I_]; near[I_] = 0; idx[I_] = 0; })
+                    for (int l = 0; l < 64; ++l) {
+                        const uint32_t hl = RL(h, l), pl = RL(prev, l), sl = RL(slot, l); const int al = RL(act, l);
+                        LANES({
+                            if (al && act[I_] && h[I_] == hl) {
+                                if (pl < gmin[I_]) gmin[I_] = pl;
+                                if (sl < smin[I_]) smin[I_] = sl;
+                                if (l < LANE) { near[I_] = (uint32_t)(base + l) + 1u; idx[I_]++; }
+                            }
+                        })
+                    }
+                    LANES({ prev[I_] = near[I_] ? near[I_] : gmin[I_]; slot[I_] = smin[I_] + idx[I_]; })
+                }
             }
-            LANES({ prev[I_] = near[I_] ? near[I_] : gmin[I_]; })
+            LANES({
+                const int p = base + LANE;
+                if (act[I_]) {
+                    uint32_t d = 0;
+                    if (prev[I_]) { const uint32_t dist = (uint32_t)p + 1u - prev[I_]; d = dist <= 65535u ? dist : 0u; }
+                    chain[p] = (uint16_t)d;
+                    rank[p] = slot[I_];
+                    list[slot[I_]] = (uint32_t)p | (prev[I_] ? 0u : kHc12First);
+                } else if (p >= nIns && half == 0) chain[p] = 0;
+            })
         }
-        LANES({
-            const int p = base + LANE;
-            uint32_t d = 0;
-            if (act[I_] && prev[I_]) { const uint32_t dist = (uint32_t)p + 1u - prev[I_]; d = dist <= 65535u ? dist : 0u; }
-            chain[p] = (uint16_t)d;
-        })
+        LDS_FENCE();
     }
 }
 
 // ------------------------------------------------------------------------------------------ phase 2: F(p), one lane per position
 // Chain accessors: ch(q) = the stored value of position q.
 struct Hc12Flat { const uint16_t* c; DEVM uint32_t operator()(uint32_t q) const { return c[q]; } };
-// A window of the chain in LDS: 72 chunks of 1024 entries, position q at chunk (q / 1024) % 72.  It holds [loaded - 73728, loaded).
-enum : int { kHc12RingChunk = 1024, kHc12RingChunks = 72, kHc12RingEntries = kHc12RingChunk * kHc12RingChunks };
-struct Hc12Ring {
-    const uint16_t* r;
-    DEVM uint32_t operator()(uint32_t q) const { return r[(((q >> 10) % (uint32_t)kHc12RingChunks) << 10) | (q & 1023u)]; }
-};
-
 // LZ4HC_FindLongerMatch(ip = src + pos, minLen 3, nbSearches 16384) == LZ4HC_InsertAndGetWiderMatch(lookBack 0,
 // patternAnalysis, chainSwap) on an independent block without dictionary (lz4hc.c:884-1065).  Plain per-lane code: every
 // lane of a wave runs its own position.  step() evaluates ONE candidate of the chain walk and returns true when the search
@@ -180,6 +199,280 @@ struct Hc12Lane {
             }
         }
         mi -= chainPos == 0 ? dn0 : hc12_raw(ch(mpos + chainPos));                         // :1065
+        return false;
+    }
+};
+
+
+// The same search as the kernel runs it (k_hc12_search): the candidates of a chain come from `list`, eight entries per
+// fetch; the bytes of a candidate come from a window of the source in LDS; and the search is cut into PHASES -- a loop trip of
+// a wave runs one phase's code for the lanes that are in it, so no lane waits for another lane's inner loop:
+//   kPhFilter  up to FOUR candidates: their 2-byte filter and 4-byte test (:925-932) are read together; the first one that
+//              passes goes on to kPhCount, one whose chain link is 1 to kPhPattern, the others are behind us.  The next
+//              eight entries of the chain are requested a trip before they are needed.
+//   kPhCount   LZ4_count, 16 bytes per trip
+//   kPhScan    chain swap after an improvement (:964-987): the links of the match's positions
+//   kPhRank    after a swap or a pattern jump the walk goes on in another chain: where that position sits in `list`, and
+//              the entries below it
+//   kPhPattern pattern analysis (:989-1062)
+// Positions within 32 bytes of the block's end are not run here (no wide loads there): the kernel leaves them to the parser.
+// Decisions and their order are those of Hc12Lane::step; tests/emu checks every position of every input against it.
+enum : int { kPhIdle = 0, kPhFilter = 1, kPhCount = 2, kPhScan = 3, kPhPattern = 4, kPhSlow = 5, kPhWait = 6, kPhDone = 7,
+             kPhRank = 8 };
+
+DEV uint32_t hc12_bytes16(uint64_t lo, uint64_t hi, int o)      // the two bytes at offset o (0..14) of a 16-byte value
+{
+    if (o < 7) return (uint32_t)(lo >> (8 * o)) & 0xFFFFu;
+    if (o == 7) return ((uint32_t)(lo >> 56) | ((uint32_t)hi << 8)) & 0xFFFFu;
+    return (uint32_t)(hi >> (8 * (o - 8))) & 0xFFFFu;
+}
+
+// Source bytes: the whole block (tests, and what the LDS window falls back to) ...
+struct Hc12SrcFlat {
+    const uint8_t* g;
+    DEVM uint32_t r16(uint32_t q) const { return ld16u(g + q); }
+    DEVM uint32_t r32(uint32_t q) const { return ld32u(g + q); }
+    DEVM uint64_t r64(uint32_t q) const { return ld64u(g + q); }
+    DEVM uint32_t q16(uint32_t q) const { return ld16u(g + q); }
+    DEVM uint32_t q32(uint32_t q) const { return ld32u(g + q); }
+};
+// ... or a 128 KiB ring in LDS that holds [hi - 131072, hi): position q at q & 0x1FFFF.  r16/r32/r64: reads that would run past
+// `hi` (long matches) or across the ring's end go to memory.  q16/q32: for reads known to lie inside the window (the ring's
+// first 16 bytes are mirrored behind its end, so a read may straddle it).
+enum : int { kHc12SrcRing = 131072, kHc12SrcRingPad = 16 };
+struct Hc12SrcRing {
+    const uint8_t* ring; const uint8_t* g; uint32_t hi;
+    DEVM bool in(uint32_t q, uint32_t len) const { return q + len <= hi && (q & (kHc12SrcRing - 1)) + len <= (uint32_t)kHc12SrcRing; }
+    DEVM uint32_t r16(uint32_t q) const { return in(q, 2) ? ld16u(ring + (q & (kHc12SrcRing - 1))) : ld16u(g + q); }
+    DEVM uint32_t r32(uint32_t q) const { return in(q, 4) ? ld32u(ring + (q & (kHc12SrcRing - 1))) : ld32u(g + q); }
+    DEVM uint64_t r64(uint32_t q) const { return in(q, 8) ? ld64u(ring + (q & (kHc12SrcRing - 1))) : ld64u(g + q); }
+    DEVM uint32_t q16(uint32_t q) const { return ld16u(ring + (q & (kHc12SrcRing - 1))); }
+    DEVM uint32_t q32(uint32_t q) const { return ld32u(ring + (q & (kHc12SrcRing - 1))); }
+};
+
+struct Hc12Tabs { const uint8_t* src; const uint16_t* chain; const uint32_t* rank; const uint32_t* list; };   // global memory
+
+template <class Src>
+struct Hc12Walk {
+    uint64_t ip0, ip1;                      // [ip, ip + 16)
+    uint32_t pos, ipIndex, lowest, mi, chainPos, pattern, ip16, srcPatLen, dn0;
+    uint32_t b[8];                          // the entries below the current candidate in its chain's list, nearest first
+    uint32_t pe[8];                         // the eight entries below those, requested ahead (pePending)
+    int nb, listEnded, pePending;           // entries in b; b ends with the chain's first position: nothing more to fetch
+    uint32_t cursor;                        // list index of the entry right above the next fetch
+    int lim, longest, offset, attempts, repeat, cnt, phase;
+
+    DEVM void init(const Hc12Tabs& t, const Src& sw, int n, int p, uint32_t head)
+    {
+        pos = (uint32_t)p; lim = (n - kLastLiterals) - p;    // p + 32 <= n: the caller leaves the block's last positions to Hc12Lane
+        ip0 = sw.r64(pos); ip1 = sw.r64(pos + 8);
+        ipIndex = pos + kHcBase;
+        lowest = (kHcBase + 65536u > ipIndex) ? kHcBase : ipIndex - 65535u;
+        mi = head ? ipIndex - head : 0u;
+        chainPos = 0; pattern = (uint32_t)ip0; longest = kMinMatch - 1; offset = 0;
+        attempts = kHc12Searches; repeat = 0; srcPatLen = 0; cnt = 0; dn0 = 0;
+        ip16 = hc12_bytes16(ip0, ip1, longest - 1);
+        nb = 0; listEnded = 1; pePending = 0; cursor = 0; after_rank_down = 0;
+        phase = kPhFilter;
+        if (!head) return;                               // no candidate: the filter phase ends the search
+        cursor = pos; after_rank_down = 1;               // the first candidate is the entry below pos in pos's own chain
+        rank_trip(t);
+    }
+    DEVM Hc12F result() const
+    {
+        Hc12F f; f.len = longest > kMinMatch - 1 ? longest : 0; f.off = f.len ? offset : 0; return f;
+    }
+    DEVM void pop(int k)                     // drop the k nearest entries
+    {
+        if (k == 4) { b[0] = b[4]; b[1] = b[5]; b[2] = b[6]; b[3] = b[7]; }
+        else for (int i = 0; i < k; ++i) { for (int j = 0; j < 7; ++j) b[j] = b[j + 1]; }
+        nb -= k;
+    }
+    // e[0..8): the entries list[lo .. lo + 8), i.e. the eight below `cursor`; nearest first into b.  An entry that is the first of
+    // its hash ends the chain; what lies below it in the list belongs to another hash.
+    DEVM void take(const uint32_t (&e)[8])
+    {
+        nb = 8; listEnded = 0;
+        for (int j = 7; j >= 0; --j) if (!listEnded && (e[j] & kHc12First)) { nb = 8 - j; listEnded = 1; }
+        for (int k = 0; k < 8; ++k) b[k] = e[7 - k] & ~kHc12First;
+        cursor -= 8u;
+    }
+    // kPhRank: cursor holds a POSITION of the chain the walk goes on in; the current candidate is that position or
+    // (after_rank_down) the entry below it.  Its place in the list, whether the chain ends with it, and the entries below it.
+    // (`list` has 8 readable entries in front of index 0.)
+    int after_rank_down;
+    DEVM void rank_trip(const Hc12Tabs& t)
+    {
+        cursor = t.rank[cursor] - (uint32_t)after_rank_down;
+        after_rank_down = 0; pePending = 0;
+        const int lo = (int)cursor - 8;
+        uint32_t e[8];
+        for (int j = 0; j < 8; ++j) e[j] = t.list[lo + j];
+        phase = kPhFilter;
+        if (t.list[(int)cursor] & kHc12First) { nb = 0; listEnded = 1; return; }
+        take(e);
+    }
+    // successor of the current candidate in the followed chain -> dn0 as liblz4's table would give it (:988, :1065)
+    DEVM uint32_t link_of(uint32_t m, uint32_t succ, bool has) const
+    {
+        const uint32_t q2 = m - kHcBase + chainPos;
+        const uint32_t d = has ? q2 - succ : 65535u;
+        return d < 65535u ? d : 65535u;
+    }
+    DEVM void advance()                                                                     // :1065
+    {
+        mi -= dn0;
+        if (nb > 0) pop(1); else listEnded = 1;
+        phase = kPhFilter;
+    }
+    DEVM void after() { if (dn0 == 1 && chainPos == 0) phase = kPhPattern; else advance(); }
+    DEVM void conclude(const Src& sw, int mlen)                                              // :934-939, then what comes next
+    {
+        if (mlen > longest) {
+            longest = mlen; offset = (int)(ipIndex - mi);
+            ip16 = longest - 1 <= 14 ? hc12_bytes16(ip0, ip1, longest - 1) : sw.r16(pos + (uint32_t)longest - 1u);
+        }
+        if (mlen == longest && mi + (uint32_t)longest <= ipIndex) { phase = kPhScan; return; }
+        after();
+    }
+    // Up to four candidates at once.  kNear: every byte looked at lies inside the source window (longest <= 60): plain LDS
+    // reads, all eight issued together.  Returns true when the search has ended.
+    template <bool kNear>
+    DEVM bool filter_trip(const Hc12Tabs& t, const Src& sw)
+    {
+        if (nb == 0 && !listEnded) {                      // the entries requested a trip ago (or right now, if none were)
+            if (!pePending) { const int lo = (int)cursor - 8; for (int j = 0; j < 8; ++j) pe[j] = t.list[lo + j]; }
+            pePending = 0;
+            take(pe);
+        }
+        if (nb <= 4 && !listEnded && !pePending) {        // ask for the next eight now, use them next trip
+            const int lo = (int)cursor - 8;
+            for (int j = 0; j < 8; ++j) pe[j] = t.list[lo + j];
+            pePending = 1;
+        }
+        // the next candidates and their links, as far as the fetched entries go: candidate k needs entry k
+        const int can = (listEnded || nb >= 4) ? 4 : nb;
+        uint32_t m[5], d[4], t16[4], m32[4];
+        m[0] = mi;
+        for (int k = 0; k < 4; ++k) { d[k] = link_of(m[k], k < nb ? b[k] : 0u, k < nb); m[k + 1] = m[k] - d[k]; }
+        const uint32_t o = (uint32_t)longest - 1u;
+        for (int k = 0; k < 4; ++k) {
+            const bool live = k < can && m[k] >= lowest && m[k] < ipIndex;   // (a dead one is never looked at: the search ends before)
+            const uint32_t q = live ? m[k] - kHcBase : pos;
+            if (kNear) { t16[k] = sw.q16(q + o); m32[k] = sw.q32(q); }
+            else       { t16[k] = sw.r16(q + o); m32[k] = sw.r32(q); }
+        }
+        // what happens at candidate k, in the order of :918-:1065: 1 the walk is over; 2 it passes the tests -> count;
+        // 3 its link is 1 -> pattern analysis; 0 it is behind us.  The first k with an event decides.
+        int ev = 0, at = can;
+        for (int k = 3; k >= 0; --k) {
+            const int dead = !(m[k] >= lowest && attempts > k);
+            const int pass = t16[k] == ip16 && m32[k] == pattern;
+            const int pat  = d[k] == 1u && chainPos == 0u;
+            const int e = dead ? 1 : (pass ? 2 : (pat ? 3 : 0));
+            if (k < can && e) { ev = e; at = k; }
+        }
+        if (ev == 1) { attempts -= at; phase = kPhIdle; return true; }
+        if (ev) {
+            attempts -= at + 1;
+            mi = at == 0 ? m[0] : (at == 1 ? m[1] : (at == 2 ? m[2] : m[3]));
+            dn0 = at == 0 ? d[0] : (at == 1 ? d[1] : (at == 2 ? d[2] : d[3]));
+            pop(at);
+            cnt = kMinMatch; phase = ev == 2 ? kPhCount : kPhPattern;
+            return false;
+        }
+        // all of them are behind us
+        attempts -= can;
+        mi = can == 1 ? m[1] : (can == 2 ? m[2] : (can == 3 ? m[3] : m[4]));
+        if (nb >= can) pop(can); else { nb = 0; listEnded = 1; }
+        return false;
+    }
+    DEVM bool is_near() const { return longest <= 60; }
+    DEVM void count_trip(const Hc12Tabs& t, const Src& sw)
+    {
+        const uint32_t mpos = mi - kHcBase;
+        if (cnt + 16 > lim) {                            // the last bytes before the limit: the plain count
+            conclude(sw, cnt + hc_count(t.src + pos + cnt, t.src + mpos + cnt, t.src + pos + lim));
+            return;
+        }
+        const uint64_t x0 = sw.r64(pos + (uint32_t)cnt) ^ sw.r64(mpos + (uint32_t)cnt);
+        const uint64_t x1 = sw.r64(pos + (uint32_t)cnt + 8u) ^ sw.r64(mpos + (uint32_t)cnt + 8u);
+        if (x0) { conclude(sw, cnt + (ctz64(x0) >> 3)); return; }
+        if (x1) { conclude(sw, cnt + 8 + (ctz64(x1) >> 3)); return; }
+        cnt += 16;
+        if (cnt >= lim) conclude(sw, lim);
+    }
+    DEVM bool scan_trip(const Hc12Tabs& t)                                                   // :964-987
+    {
+        const uint32_t mpos = mi - kHcBase;
+        const int end = longest - kMinMatch + 1;
+        uint32_t distNext = 1;
+        if (end <= 16) {                                 // the step stays 1: every link of the match, then first-maximum
+            uint32_t e[16];
+            for (int j = 0; j < 16; ++j) e[j] = j < end ? hc12_raw(t.chain[mpos + (uint32_t)j]) : 0u;
+            for (int j = 0; j < 16; ++j) if (e[j] > distNext) { distNext = e[j]; chainPos = (uint32_t)j; }
+        } else {
+            int stepw = 1, accel = 1 << 4;
+            for (int p2 = 0; p2 < end; p2 += stepw) {
+                const uint32_t cd = hc12_raw(t.chain[mpos + (uint32_t)p2]);
+                stepw = (accel++ >> 4);
+                if (cd > distNext) { distNext = cd; chainPos = (uint32_t)p2; accel = 1 << 4; }
+            }
+        }
+        if (distNext > 1) {
+            if (distNext > mi) { phase = kPhIdle; return true; }
+            const uint32_t q2 = mpos + chainPos;         // the walk goes on in this position's chain
+            mi -= distNext;
+            nb = 0;
+            if (distNext >= 65535u) { listEnded = 1; pePending = 0; phase = kPhFilter; }   // (a saturated link: the next test ends the search)
+            else { listEnded = 0; pePending = 0; cursor = q2; phase = kPhRank; after_rank_down = 1; }
+            return false;
+        }
+        after();
+        return false;
+    }
+    DEVM bool pattern_trip(const Hc12Tabs& t, const Src& sw)                                 // :989-1062, dn0 == 1 && chainPos == 0
+    {
+        const uint8_t* const ip = t.src + pos;
+        const uint8_t* const iHigh = ip + lim;
+        const uint32_t mci = mi - 1;
+        if (repeat == 0) {
+            if (((pattern & 0xFFFFu) == (pattern >> 16)) & ((pattern & 0xFFu) == (pattern >> 24))) {
+                repeat = 2;
+                srcPatLen = hc_count_pattern(ip + 4, iHigh, pattern) + 4;
+            } else repeat = 1;
+        }
+        if (repeat == 2 && mci >= lowest) {
+            const uint8_t* const mq = t.src + (mci - kHcBase);
+            if (ld32u(mq) == pattern) {
+                const uint32_t fwd = hc_count_pattern(mq + 4, iHigh, pattern) + 4;
+                uint32_t back = hc_rcount_pattern(mq, t.src, pattern);
+                {   const uint32_t far = mci - back;
+                    back = mci - (far > lowest ? far : lowest); }
+                const uint32_t seg = back + fwd;
+                nb = 0; listEnded = 0; after_rank_down = 0; pePending = 0;
+                if (seg >= srcPatLen && fwd <= srcPatLen) {
+                    mi = mci + fwd - srcPatLen;                                        // this candidate is looked at next
+                    cursor = mi - kHcBase; phase = kPhRank;
+                } else {
+                    mi = mci - back;
+                    const uint32_t maxML = seg < srcPatLen ? seg : srcPatLen;
+                    if ((uint32_t)longest < maxML) {
+                        if (ipIndex - mi > 65535u) { phase = kPhIdle; return true; }
+                        longest = (int)maxML; offset = (int)(ipIndex - mi);
+                        ip16 = longest - 1 <= 14 ? hc12_bytes16(ip0, ip1, longest - 1) : sw.r16(pos + (uint32_t)longest - 1u);
+                    }
+                    const uint32_t at = mi - kHcBase;
+                    const uint32_t dp = hc12_raw(t.chain[at]);
+                    if (dp > mi) { phase = kPhIdle; return true; }
+                    mi -= dp;
+                    if (dp >= 65535u) { listEnded = 1; phase = kPhFilter; }
+                    else { cursor = at; after_rank_down = 1; phase = kPhRank; }
+                }
+                return false;
+            }
+        }
+        advance();
         return false;
     }
 };

@@ -53,6 +53,9 @@ struct CodecArgs {
     // level 12 in three phases (lz4hc12_device.inl): per-block chain and search results of the group [blk0, blk0 + nBlocks)
     int             blk0;
     uint16_t*       h12Chain;   int64_t h12ChainStride;      // entries per block (a multiple of 1024)
+    uint32_t*       h12Rank;                                 // h12ChainStride entries per block
+    uint32_t*       h12List;                                 // h12ChainStride + 8 entries per block (8 readable entries in front of index 0)
+    uint32_t*       h12Offsets;                              // 32768 per block: where each hash's run starts in the list
     Hc12F*          h12F;       int64_t h12FStride;          // entries per block
     uint8_t*        h12Ws;                                   // gridDim.x x kHc12WsGlobalBytes: the price table's overflow
     int32_t*        h12Err;                                  // set when a kernel gives up (spin guard)
@@ -348,23 +351,65 @@ __global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------- HC level 12, three phases
-// Phase 1: the chain of every block of the group.  One wave per workgroup, the 128 KiB hash table in LDS (one block per CU).
+// Phase 1a: how many positions every hash has, then where its run starts in the list (exclusive prefix sum).  One 16-wave
+// workgroup per block, the 32768 counters in LDS.
+__global__ __launch_bounds__(1024) void k_hc12_hist(CodecArgs a)
+{
+    __shared__ uint32_t hist[kHcHashEntries];
+    __shared__ uint32_t part[1024];
+    __shared__ int cur;
+    const int tid = (int)threadIdx.x;
+    for (;;) {
+        if (tid == 0) cur = (int)atomicAdd(a.queue, 1u);
+        __syncthreads();
+        const int g = cur;
+        if (g >= a.nBlocks) break;
+        const int i = a.blk0 + g;
+        const int n = block_len(a, i);
+        const uint8_t* const src = a.src + (int64_t)i * a.srcStride;
+        for (int h = tid; h < kHcHashEntries; h += 1024) hist[h] = 0u;
+        __syncthreads();
+        const int nIns = n >= 4 ? n - 3 : 0;
+        for (int p = tid; p < nIns; p += 1024) atomicAdd(&hist[hc12_hash(ld32u(src + p))], 1u);
+        __syncthreads();
+        uint32_t sum = 0;
+        for (int k = 0; k < 32; ++k) sum += hist[tid * 32 + k];
+        part[tid] = sum;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint32_t v = (tid >= d) ? part[tid - d] : 0u;
+            __syncthreads();
+            part[tid] += v;
+            __syncthreads();
+        }
+        uint32_t run = part[tid] - sum;
+        uint32_t* const off = a.h12Offsets + (size_t)g * kHcHashEntries;
+        for (int k = 0; k < 32; ++k) { const uint32_t c = hist[tid * 32 + k]; off[tid * 32 + k] = run; run += c; }
+        __syncthreads();
+    }
+}
+
+// Phase 1b: chain, rank and list of every block of the group.  One wave per workgroup, two 64 KiB tables in LDS.
 __global__ __launch_bounds__(64) void k_hc12_chain(CodecArgs a)
 {
-    __shared__ uint32_t tab[kHcHashEntries];
+    __shared__ uint32_t lastT[kHcHashEntries / 2];
+    __shared__ uint32_t curT[kHcHashEntries / 2];
     for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
         const int i = a.blk0 + g;
         const int n = block_len(a, i);
         int nPad = (n + 1 + 1023) & ~1023;
         if (nPad > a.h12ChainStride) nPad = (int)a.h12ChainStride;
-        hc12_build_chain(a.src + (int64_t)i * a.srcStride, n, a.h12Chain + (int64_t)g * a.h12ChainStride, nPad, tab);
+        hc12_build_lists(a.src + (int64_t)i * a.srcStride, n, a.h12Offsets + (size_t)g * kHcHashEntries,
+                         a.h12Chain + (int64_t)g * a.h12ChainStride, a.h12Rank + (int64_t)g * a.h12ChainStride,
+                         a.h12List + (int64_t)g * (a.h12ChainStride + 8) + 8, nPad, lastT, curT);
     }
 }
 
-// Phase 2: F(p) for the positions of every block of the group.  One 16-wave workgroup per block at a time; the chain of the
-// 64 KiB behind the positions in flight sits in LDS (a ring of 72 x 1024 entries fed from phase 1's array), the source bytes
-// come through L2.  Every lane runs one position (Hc12Lane), one chain step per loop trip; a lane that has finished takes the
-// next position from the block's queue in the same trip, so lanes never wait for the longest chain of their wave.
+// Phase 2: F(p) for the positions of every block of the group.  One 16-wave workgroup per block at a time; the 64 KiB of source
+// behind the positions in flight (and what lies ahead of them) sit in a 128 KiB ring in LDS, fed 1 KiB at a time; the chains
+// come from the lists of phase 1.  Every lane runs one position (Hc12Walk); a loop trip runs each phase's code once for the
+// lanes that are in it; a lane that has finished takes the next position from the block's queue, so lanes never wait for the
+// longest search of their wave.
 struct Hc12Ctl { int qNext; int loaded; int skipUntil; int lock; int waveMin[16]; int cur; };
 
 __device__ __forceinline__ int h12_wave_min(int v)
@@ -385,7 +430,7 @@ __device__ __forceinline__ int h12_wave_min(int v)
 
 __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t ring[kHc12RingEntries];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[kHc12SrcRing + kHc12SrcRingPad];
     __shared__ Hc12Ctl ctl;
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (;;) {
@@ -395,32 +440,46 @@ __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
         if (g >= a.nBlocks) break;
         const int i = a.blk0 + g;
         const int n = block_len(a, i);
-        const uint8_t* const src = a.src + (int64_t)i * a.srcStride;
-        const uint16_t* const chain = a.h12Chain + (int64_t)g * a.h12ChainStride;
+        Hc12Tabs t;
+        t.src = a.src + (int64_t)i * a.srcStride;
+        t.chain = a.h12Chain + (int64_t)g * a.h12ChainStride;
+        t.rank = a.h12Rank + (int64_t)g * a.h12ChainStride;
+        t.list = a.h12List + (int64_t)g * (a.h12ChainStride + 8) + 8;
         Hc12F* const F = a.h12F + (int64_t)g * a.h12FStride;
         const int nPos = n - kMfLimit + 1 > 0 ? n - kMfLimit + 1 : 0;                // positions the parser can search
-        int nChain = (n + 1 + 1023) & ~1023;
-        if (nChain > a.h12ChainStride) nChain = (int)a.h12ChainStride;
         if (tid == 0) { ctl.qNext = 0; ctl.loaded = 0; ctl.skipUntil = 0; ctl.lock = 0; }
         if (tid < 16) ctl.waveMin[tid] = 0;
         __syncthreads();
 
-        Hc12Ring ch; ch.r = ring;
-        Hc12Lane<Hc12Ring> L;
-        int st = 0, p = 0;                      // 0 idle, 1 searching p, 2 holds p and waits for its chain, 3 no positions left
+        Hc12SrcRing sw; sw.ring = ring; sw.g = t.src; sw.hi = 0;
+        Hc12Walk<Hc12SrcRing> L;
+        L.phase = kPhIdle;                      // kPhIdle: wants a position; kPhWait: holds p, its bytes are not in the ring yet
+        int p = 0;
         unsigned idleTrips = 0;
+        auto finish = [&]() {                   // the lane's search has ended: publish F(p)
+            const Hc12F f = L.result();
+            F[p] = f;
+            if (f.len > kHc12Sufficient + 8) atomicMax(&ctl.skipUntil, p + f.len - kHc12Sufficient);
+        };
         for (;;) {
-            if (__builtin_amdgcn_ballot_w64(st == 0 || st == 2)) {
+            const uint64_t mF = __builtin_amdgcn_ballot_w64(L.phase == kPhFilter);
+            const uint64_t mC = __builtin_amdgcn_ballot_w64(L.phase == kPhCount);
+            const uint64_t mS = __builtin_amdgcn_ballot_w64(L.phase == kPhScan);
+            const uint64_t mK = __builtin_amdgcn_ballot_w64(L.phase == kPhRank);
+            const uint64_t mP = __builtin_amdgcn_ballot_w64(L.phase == kPhPattern);
+            const uint64_t mI = __builtin_amdgcn_ballot_w64(L.phase == kPhIdle || L.phase == kPhWait);
+            const bool busy = (mF | mC | mS | mK | mP) != 0;
+            if (mI && (__builtin_popcountll(mI) >= 16 || !busy)) {
                 // (1) this wave's lower bound on the positions it holds or may still take: published BEFORE it takes new ones
                 const int q0 = H12_LD(ctl.qNext);
-                int m = h12_wave_min((st == 1 || st == 2) ? p : 0x7FFFFFFF);
+                int m = h12_wave_min((L.phase != kPhIdle && L.phase != kPhDone) ? p : 0x7FFFFFFF);
                 if (q0 < m) m = q0;
                 if (lane == 0) H12_ST(ctl.waveMin[wv], m);
                 H12_ORDER();
-                // (2) keep the ring ahead of the queue: one wave at a time loads the next chunks.  The ring must still hold
-                // [p - 65535, p] of every position p in flight or yet to be taken: loaded - ring <= min(p) - 65535.
+                // (2) keep the ring ahead of the queue: one wave at a time loads the next KiBs.  The ring must still hold the
+                // 64 KiB behind every position in flight or yet to be taken: loaded - ring <= min(p) - 65535.
                 int loaded = H12_LD(ctl.loaded);
-                if (loaded < nChain && loaded < q0 + 2048) {
+                if (loaded < n && loaded < q0 + 8192) {
                     int got = 0;
                     if (lane == 0) got = atomicCAS(&ctl.lock, 0, 1) == 0;
                     if (__builtin_amdgcn_readfirstlane(got)) {
@@ -429,45 +488,64 @@ __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
                         H12_ORDER();
                         int mn = h12_wave_min(lane < 16 ? H12_LD(ctl.waveMin[lane]) : 0x7FFFFFFF);
                         if (qn < mn) mn = qn;
-                        while (loaded < nChain && loaded < qn + 4096 && loaded + kHc12RingChunk <= mn + (kHc12RingEntries - 65536)) {
-                            const uint4* gsrc = (const uint4*)(chain + loaded);
-                            uint4* ldst = (uint4*)(ring + ((((uint32_t)loaded >> 10) % (uint32_t)kHc12RingChunks) << 10));
-                            const uint4 v0 = gsrc[lane], v1 = gsrc[lane + 64];
-                            ldst[lane] = v0; ldst[lane + 64] = v1;
-                            loaded += kHc12RingChunk;
+                        while (loaded < n && loaded < qn + 16384 && loaded + 1024 <= mn + 65536) {
+                            const int at = loaded + lane * 16;
+                            uint8_t* d = ring + (at & (kHc12SrcRing - 1));
+                            if (at + 16 <= n) {
+                                const uint4 v = *(const uint4*)(t.src + at);
+                                *(uint4*)d = v;
+                                if ((at & (kHc12SrcRing - 1)) == 0) *(uint4*)(ring + kHc12SrcRing) = v;           // the mirror behind the ring's end
+                            } else for (int k = 0; k < 16; ++k) if (at + k < n) { d[k] = t.src[at + k]; if ((at & (kHc12SrcRing - 1)) == 0) ring[kHc12SrcRing + k] = d[k]; }
+                            loaded += 1024;
                         }
                         H12_ORDER();
                         if (lane == 0) { H12_ST(ctl.loaded, loaded); H12_ORDER(); atomicExch(&ctl.lock, 0); }
                     }
                 }
                 // (3) idle lanes take the next positions
-                const uint64_t idle = __builtin_amdgcn_ballot_w64(st == 0);
+                const uint64_t idle = __builtin_amdgcn_ballot_w64(L.phase == kPhIdle);
                 if (idle) {
                     const int first = __builtin_ctzll(idle);
                     int base = 0;
                     if (lane == first) base = atomicAdd(&ctl.qNext, __builtin_popcountll(idle));
                     base = __builtin_amdgcn_readlane(base, first);
-                    if (st == 0) { p = base + __builtin_popcountll(idle & ((1ull << lane) - 1)); st = p < nPos ? 2 : 3; }
+                    if (L.phase == kPhIdle) {
+                        p = base + __builtin_popcountll(idle & ((1ull << lane) - 1));
+                        L.phase = p < nPos ? kPhWait : kPhDone;
+                        // (the block's last positions -- no wide loads there -- are the parser's)
+                        if (p < nPos && p + 32 > n) { Hc12F f; f.len = kHc12NotComputed; f.off = 0; F[p] = f; L.phase = kPhIdle; }
+                    }
                 }
-                // (4) a lane starts its position once the chain up to it is in the ring; positions inside a match longer than
+                // (4) a lane starts its position once the bytes around it are in the ring; positions inside a match longer than
                 // the parser's "sufficient" length are left to the parser (it jumps over them, lz4hc.c:1871-1882)
                 loaded = H12_LD(ctl.loaded);
                 const int skip = H12_LD(ctl.skipUntil);
-                if (st == 2) {
-                    if (p < skip) { Hc12F f; f.len = kHc12NotComputed; f.off = 0; F[p] = f; st = 0; }
-                    else if (p < loaded) { L.init(src, n, p, ch((uint32_t)p)); st = 1; }
+                sw.hi = (uint32_t)(loaded < n ? loaded : n);
+                if (L.phase == kPhWait) {
+                    if (p < skip) { Hc12F f; f.len = kHc12NotComputed; f.off = 0; F[p] = f; L.phase = kPhIdle; }
+                    else if (p + 64 <= loaded || loaded >= n) L.init(t, sw, n, p, (uint32_t)t.chain[p]);
                 }
             }
-            if (!__builtin_amdgcn_ballot_w64(st != 3)) break;
-            if (st == 1) {
-                if (L.step(ch)) {
-                    const Hc12F f = L.result();
-                    F[p] = f;
-                    st = 0;
-                    if (f.len > kHc12Sufficient + 8) atomicMax(&ctl.skipUntil, p + f.len - kHc12Sufficient);
+            if (!__builtin_amdgcn_ballot_w64(L.phase != kPhDone)) break;
+            sw.hi = (uint32_t)min(H12_LD(ctl.loaded), n);
+            // One phase's code per section.  A section costs the same whether 3 or 60 lanes are in it, so it runs when enough
+            // lanes have gathered; when no phase has that many, the fullest one runs (nothing ever waits for good).
+            {
+                const int cF = __builtin_popcountll(mF), cC = __builtin_popcountll(mC), cS = __builtin_popcountll(mS),
+                          cK = __builtin_popcountll(mK), cP = __builtin_popcountll(mP);
+                int top = cF; top = cC > top ? cC : top; top = cS > top ? cS : top; top = cK > top ? cK : top; top = cP > top ? cP : top;
+                const int need = top < 12 ? top : 12;
+                if (cF && cF >= need) {
+                    const bool fl = L.phase == kPhFilter;
+                    if (__builtin_amdgcn_ballot_w64(fl && !L.is_near())) { if (fl && !L.is_near() && L.filter_trip<false>(t, sw)) finish(); }
+                    if (fl && L.is_near() && L.filter_trip<true>(t, sw)) finish();
                 }
+                if (cC && cC >= need) { if (L.phase == kPhCount) L.count_trip(t, sw); }
+                if (cS && cS >= need) { if (L.phase == kPhScan && L.scan_trip(t)) finish(); }
+                if (cK && cK >= need) { if (L.phase == kPhRank) L.rank_trip(t); }
+                if (cP && cP >= need) { if (L.phase == kPhPattern && L.pattern_trip(t, sw)) finish(); }
             }
-            if (!__builtin_amdgcn_ballot_w64(st == 1)) {
+            if (!busy) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++idleTrips > (1u << 27)) { if (lane == 0) atomicExch(a.h12Err, 1); break; }      // never seen; bounds every spin
             } else idleTrips = 0;
@@ -783,12 +861,12 @@ int hc_leave(plz4hip_ctx* c, hipStream_t s)
 // Level 12 on independent blocks without dictionary runs in three phases per group of blocks (lz4hc12_device.inl):
 // chain -> search results -> parser.  Per block the group workspace holds the chain (2 B per position) and F (8 B per
 // position); the group size follows from the memory set aside (PLZ4HIP_HC12_GROUP overrides, for tests).
-struct H12Plan { int64_t chainStride, fStride; size_t perBlock; int group; size_t offF, offWs, offErr, total; };
+struct H12Plan { int64_t chainStride, fStride; size_t perBlock; int group; size_t offRank, offList, offOffsets, offF, offWs, offErr, total; };
 int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
 {
     pl->chainStride = (int64_t)round_up((size_t)maxLen + 1, 1024);
     pl->fStride = (int64_t)round_up((size_t)(maxLen > 11 ? maxLen - 11 : 1), 64);
-    pl->perBlock = (size_t)pl->chainStride * 2 + (size_t)pl->fStride * 8;
+    pl->perBlock = (size_t)pl->chainStride * 2 + (size_t)pl->chainStride * 4 + ((size_t)pl->chainStride + 8) * 4 + (size_t)kHcHashEntries * 4 + (size_t)pl->fStride * 8;
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
     size_t budget = (freeB + c->h12Bytes) / 4;
@@ -803,7 +881,10 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc12_parse, 64, 0) != hipSuccess || per < 1) per = 8;
         c->h12ParseWaves = c->cus * per;
     }
-    pl->offF = round_up((size_t)pl->group * (size_t)pl->chainStride * 2, 256);
+    pl->offRank = round_up((size_t)pl->group * (size_t)pl->chainStride * 2, 256);
+    pl->offList = pl->offRank + round_up((size_t)pl->group * (size_t)pl->chainStride * 4, 256);
+    pl->offOffsets = pl->offList + round_up((size_t)pl->group * ((size_t)pl->chainStride + 8) * 4, 256);
+    pl->offF = pl->offOffsets + round_up((size_t)pl->group * (size_t)kHcHashEntries * 4, 256);
     pl->offWs = pl->offF + round_up((size_t)pl->group * (size_t)pl->fStride * 8, 256);
     pl->offErr = pl->offWs + round_up((size_t)c->h12ParseWaves * kHc12WsGlobalBytes, 256);
     pl->total = pl->offErr + 256;
@@ -828,13 +909,19 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         H12Plan pl;
         if (int rc = plan_h12(c, nb, maxLen, &pl)) return rc;
         a.h12Chain = (uint16_t*)c->d_h12; a.h12ChainStride = pl.chainStride;
+        a.h12Rank = (uint32_t*)(c->d_h12 + pl.offRank); a.h12List = (uint32_t*)(c->d_h12 + pl.offList);
+        a.h12Offsets = (uint32_t*)(c->d_h12 + pl.offOffsets);
         a.h12F = (Hc12F*)(c->d_h12 + pl.offF); a.h12FStride = pl.fStride;
         a.h12Ws = c->d_h12 + pl.offWs; a.h12Err = (int32_t*)(c->d_h12 + pl.offErr);
         a.rawMode = rawMode;
         HIPCHK(c, hipMemsetAsync(a.h12Err, 0, 4, s));
-        for (int g0 = 0; g0 < nb; g0 += pl.group) {
-            const int ng = nb - g0 < pl.group ? nb - g0 : pl.group;
+        const int nGroups = (nb + pl.group - 1) / pl.group;
+        const int per = (nb + nGroups - 1) / nGroups;                     // groups of equal size (<= pl.group)
+        for (int g0 = 0; g0 < nb; g0 += per) {
+            const int ng = nb - g0 < per ? nb - g0 : per;
             a.blk0 = g0; a.nBlocks = ng;
+            a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+            hipLaunchKernelGGL(k_hc12_hist, dim3(grid_for(ng, c->cus)), dim3(1024), 0, s, a);
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);
             hipLaunchKernelGGL(k_hc12_chain, dim3(grid_for(ng, c->cus)), dim3(64), 0, s, a);
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);

@@ -115,27 +115,74 @@ int emu_decode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, cons
 }
 
 // ---- HC level 12 in its three device phases (lz4hc12_device.inl), back to back on the CPU.
+#include "../../plz4_amd/csrc/lz4hc12_device.inl"
+namespace {
+struct H12Emu {
+    uint8_t* padded; uint16_t* chain; uint32_t* rank; uint32_t* listBase; uint32_t* offsets; int n, nPos, nPad;
+    plz4::Hc12Tabs tabs;
+    H12Emu(const uint8_t* src, int n_) : n(n_)
+    {
+        using namespace plz4;
+        nPos = n - kMfLimit + 1 > 0 ? n - kMfLimit + 1 : 0;
+        nPad = ((n > 0 ? n : 0) + 1 + 1023) / 1024 * 1024;
+        padded = (uint8_t*)calloc((size_t)(n > 0 ? n : 0) + 64, 1);
+        if (n > 0) memcpy(padded, src, (size_t)n);
+        chain = (uint16_t*)malloc((size_t)nPad * 2);
+        rank = (uint32_t*)malloc((size_t)nPad * 4);
+        listBase = (uint32_t*)malloc(((size_t)nPad + 8) * 4);
+        memset(listBase, 0xEE, 32);
+        offsets = (uint32_t*)calloc(kHcHashEntries, 4);
+        // what the histogram kernel does: how many positions each hash has, then where its run starts
+        const int nIns = n >= 4 ? n - 3 : 0;
+        for (int p = 0; p < nIns; ++p) offsets[hc12_hash(ld32u(padded + p))]++;
+        uint32_t run = 0;
+        for (int h = 0; h < kHcHashEntries; ++h) { const uint32_t c = offsets[h]; offsets[h] = run; run += c; }
+        uint32_t* lastT = (uint32_t*)malloc(kHcHashEntries / 2 * 4); uint32_t* curT = (uint32_t*)malloc(kHcHashEntries / 2 * 4);
+        hc12_build_lists(padded, n, offsets, chain, rank, listBase + 8, nPad, lastT, curT);
+        free(lastT); free(curT);
+        tabs.src = padded; tabs.chain = chain; tabs.rank = rank; tabs.list = listBase + 8;
+    }
+    ~H12Emu() { free(padded); free(chain); free(rank); free(listBase); free(offsets); }
+    plz4::Hc12F plain(int p) const
+    {
+        using namespace plz4;
+        Hc12Flat ch; ch.c = chain;
+        Hc12Lane<Hc12Flat> L; L.init(padded, n, p, ch((uint32_t)p));
+        while (!L.step(ch)) {}
+        return L.result();
+    }
+    plz4::Hc12F walk(int p, long* trips) const                  // the kernel's search, one lane
+    {
+        using namespace plz4;
+        if (p + 32 > n) return plain(p);                    // as the kernel: the last positions are the parser's
+        Hc12SrcFlat sw; sw.g = padded;
+        Hc12Walk<Hc12SrcFlat> Q; Q.init(tabs, sw, n, p, chain[p]);
+        for (bool done = false; !done; ) {
+            if (trips) trips[Q.phase]++;
+            switch (Q.phase) {
+            case kPhFilter:  done = Q.is_near() ? Q.filter_trip<true>(tabs, sw) : Q.filter_trip<false>(tabs, sw); break;
+            case kPhCount:   Q.count_trip(tabs, sw); break;
+            case kPhScan:    done = Q.scan_trip(tabs); break;
+            case kPhRank:    Q.rank_trip(tabs); break;
+            case kPhPattern: done = Q.pattern_trip(tabs, sw); break;
+            default:         done = true; break;
+            }
+        }
+        return Q.result();
+    }
+};
+}
 // ncEvery > 0: every ncEvery-th position is left to the parser's own search (the path for positions the search phase skips);
 // nl: entries of the price table kept in "LDS" (small values exercise the global part).
-#include "../../plz4_amd/csrc/lz4hc12_device.inl"
 extern "C" int emu_compress_hc12(const uint8_t* src, int n, uint8_t* dst, int cap, int ncEvery, int nl)
 {
     using namespace plz4;
-    const int nPos = n - kMfLimit + 1 > 0 ? n - kMfLimit + 1 : 0;
-    const int nPad = ((n > 0 ? n : 0) + 1 + 1023) / 1024 * 1024;
-    uint16_t* chain = (uint16_t*)malloc((size_t)nPad * 2);
-    uint32_t* tab = (uint32_t*)malloc((size_t)kHcHashEntries * 4);
-    uint8_t* padded = (uint8_t*)calloc((size_t)(n > 0 ? n : 0) + 64, 1);
-    if (n > 0) memcpy(padded, src, (size_t)n);
-    hc12_build_chain(padded, n, chain, nPad, tab);
-    Hc12F* F = (Hc12F*)malloc(sizeof(Hc12F) * (size_t)(nPos + 1));
-    Hc12Flat ch; ch.c = chain;
+    H12Emu E(src, n);
+    Hc12F* F = (Hc12F*)malloc(sizeof(Hc12F) * (size_t)(E.nPos + 1));
     int skipUntil = 0;                  // as the search kernel: positions inside a match longer than the parser's "sufficient" are left out
-    for (int p = 0; p < nPos; ++p) {
+    for (int p = 0; p < E.nPos; ++p) {
         if ((ncEvery > 0 && p % ncEvery == ncEvery - 1) || p < skipUntil) { F[p].len = kHc12NotComputed; F[p].off = 0; continue; }
-        Hc12Lane<Hc12Flat> L; L.init(padded, n, p, ch((uint32_t)p));
-        while (!L.step(ch)) {}
-        F[p] = L.result();
+        F[p] = E.walk(p, nullptr);
         if (F[p].len > kHc12Sufficient + 8 && p + F[p].len - kHc12Sufficient > skipUntil) skipUntil = p + F[p].len - kHc12Sufficient;
     }
     Hc12Ws w;
@@ -143,8 +190,24 @@ extern "C" int emu_compress_hc12(const uint8_t* src, int n, uint8_t* dst, int ca
     w.price = (int*)malloc(4 * (size_t)nl); w.litlen = (int*)malloc(4 * (size_t)nl); w.mloff = (uint32_t*)malloc(4 * (size_t)nl);
     w.gprice = (int*)malloc(4 * kHc12OptEntries); w.glitlen = (int*)malloc(4 * kHc12OptEntries); w.gmloff = (uint32_t*)malloc(4 * kHc12OptEntries);
     uint64_t seq[64]; w.seq = seq;
-    const int r = hc12_parse(padded, n, dst, cap, F, chain, w);
+    const int r = hc12_parse(E.padded, n, dst, cap, F, E.chain, w);
     free(w.price); free(w.litlen); free(w.mloff); free(w.gprice); free(w.glitlen); free(w.gmloff);
-    free(F); free(padded); free(tab); free(chain);
+    free(F);
     return r;
+}
+
+// The search as the kernel runs it (Hc12Walk: lists, phases) against the plain chain walk (Hc12Lane), every position of the
+// block: returns the number of positions whose answers differ.  trips (optional, 10 counters): phase trips in all.
+extern "C" int emu_hc12_search_check(const uint8_t* src, int n, long* trips)
+{
+    using namespace plz4;
+    H12Emu E(src, n);
+    int bad = 0, skipUntil = 0;
+    for (int p = 0; p < E.nPos; ++p) {
+        if (p < skipUntil) continue;
+        const Hc12F a = E.plain(p), b = E.walk(p, trips);
+        if (a.len != b.len || a.off != b.off) bad++;
+        if (a.len > kHc12Sufficient + 8 && p + a.len - kHc12Sufficient > skipUntil) skipUntil = p + a.len - kHc12Sufficient;
+    }
+    return bad;
 }

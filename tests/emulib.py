@@ -98,3 +98,9 @@ class Emu:
         dst = np.empty(max(cap, 1) + 64, dtype=np.uint8)
         r = int(self.L.emu_compress_hc12(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, nc_every, nl))
         return r, dst[:max(r, 0)]
+
+    def hc12_search_check(self, src):
+        """Positions whose phased search (Hc12Walk, what k_hc12_search runs) differs from the plain one (Hc12Lane)."""
+        self.L.emu_hc12_search_check.restype = C.c_int
+        self.L.emu_hc12_search_check.argtypes = [u8p, C.c_int, C.c_void_p]
+        return int(self.L.emu_hc12_search_check(_ptr(src) if src.size else C.cast(None, u8p), src.size, None))
