@@ -251,6 +251,12 @@ struct Hc12SrcRing {
 };
 
 struct Hc12Tabs { const uint8_t* src; const uint16_t* chain; const uint32_t* rank; const uint32_t* list; };   // global memory
+// eight consecutive list entries / sixteen consecutive chain links as two 16-byte loads (one request per lane each, not eight)
+DEV void hc12_ld8(const uint32_t* p, uint32_t (&e)[8])
+{
+    const v16u_t a = *(const v16u_t*)p, b = *(const v16u_t*)(p + 4);
+    e[0] = a.w[0]; e[1] = a.w[1]; e[2] = a.w[2]; e[3] = a.w[3]; e[4] = b.w[0]; e[5] = b.w[1]; e[6] = b.w[2]; e[7] = b.w[3];
+}
 
 template <class Src>
 struct Hc12Walk {
@@ -307,7 +313,7 @@ struct Hc12Walk {
         after_rank_down = 0; pePending = 0;
         const int lo = (int)cursor - 8;
         uint32_t e[8];
-        for (int j = 0; j < 8; ++j) e[j] = t.list[lo + j];
+        hc12_ld8(t.list + lo, e);
         phase = kPhFilter;
         if (t.list[(int)cursor] & kHc12First) { nb = 0; listEnded = 1; return; }
         take(e);
@@ -341,13 +347,12 @@ struct Hc12Walk {
     DEVM bool filter_trip(const Hc12Tabs& t, const Src& sw)
     {
         if (nb == 0 && !listEnded) {                      // the entries requested a trip ago (or right now, if none were)
-            if (!pePending) { const int lo = (int)cursor - 8; for (int j = 0; j < 8; ++j) pe[j] = t.list[lo + j]; }
+            if (!pePending) hc12_ld8(t.list + ((int)cursor - 8), pe);
             pePending = 0;
             take(pe);
         }
-        if (nb <= 4 && !listEnded && !pePending) {        // ask for the next eight now, use them next trip
-            const int lo = (int)cursor - 8;
-            for (int j = 0; j < 8; ++j) pe[j] = t.list[lo + j];
+        if (!listEnded && !pePending) {                   // ask for the next eight as soon as the last request has been taken
+            hc12_ld8(t.list + ((int)cursor - 8), pe);
             pePending = 1;
         }
         // the next candidates and their links, as far as the fetched entries go: candidate k needs entry k
@@ -378,7 +383,18 @@ struct Hc12Walk {
             mi = at == 0 ? m[0] : (at == 1 ? m[1] : (at == 2 ? m[2] : m[3]));
             dn0 = at == 0 ? d[0] : (at == 1 ? d[1] : (at == 2 ? d[2] : d[3]));
             pop(at);
-            cnt = kMinMatch; phase = ev == 2 ? kPhCount : kPhPattern;
+            if (ev == 3) { phase = kPhPattern; return false; }
+            // the first 16 bytes of the count right here (most matches end inside them); longer ones go on in kPhCount
+            const uint32_t mq = mi - kHcBase;
+            uint64_t c0, c1;
+            if (kNear) { c0 = (uint64_t)sw.q32(mq + 4) | ((uint64_t)sw.q32(mq + 8) << 32); c1 = sw.q32(mq + 12); }
+            else       { c0 = (uint64_t)sw.r32(mq + 4) | ((uint64_t)sw.r32(mq + 8) << 32); c1 = sw.r32(mq + 12); }
+            const uint64_t x0 = c0 ^ ((ip0 >> 32) | (ip1 << 32));
+            const uint32_t x1 = (uint32_t)c1 ^ (uint32_t)(ip1 >> 32);
+            const int c = x0 ? 4 + (ctz64(x0) >> 3) : (x1 ? 12 + (__builtin_ctz(x1) >> 3) : 16);
+            if (c == 16 && lim > 16) { cnt = 16; phase = kPhCount; return false; }
+            phase = kPhFilter;
+            conclude(sw, c < lim ? c : lim);
             return false;
         }
         // all of them are behind us
@@ -408,9 +424,12 @@ struct Hc12Walk {
         const int end = longest - kMinMatch + 1;
         uint32_t distNext = 1;
         if (end <= 16) {                                 // the step stays 1: every link of the match, then first-maximum
-            uint32_t e[16];
-            for (int j = 0; j < 16; ++j) e[j] = j < end ? hc12_raw(t.chain[mpos + (uint32_t)j]) : 0u;
-            for (int j = 0; j < 16; ++j) if (e[j] > distNext) { distNext = e[j]; chainPos = (uint32_t)j; }
+            uint32_t w[8];                               // (chain[] is padded: 16 entries from any position of the block are readable)
+            hc12_ld8((const uint32_t*)(t.chain + mpos), w);
+            for (int j = 0; j < 16; ++j) {
+                const uint32_t e = j < end ? hc12_raw((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) : 0u;
+                if (e > distNext) { distNext = e; chainPos = (uint32_t)j; }
+            }
         } else {
             int stepw = 1, accel = 1 << 4;
             for (int p2 = 0; p2 < end; p2 += stepw) {
@@ -491,6 +510,13 @@ enum : int { kHc12WsGlobalBytes = kHc12OptEntries * 12 };
 #define HC12_PRICE(i)  ((i) < w.nl ? w.price[(i)]  : w.gprice[(i) - w.nl])
 #define HC12_LITLEN(i) ((i) < w.nl ? w.litlen[(i)] : w.glitlen[(i) - w.nl])
 #define HC12_MLOFF(i)  ((i) < w.nl ? w.mloff[(i)]  : w.gmloff[(i) - w.nl])
+// K (a compile-time flag): every index of this step lies below w.nl, i.e. in LDS
+#define HC12K_PRICE(i)  (K ? w.price[(i)]  : HC12_PRICE(i))
+#define HC12K_LITLEN(i) (K ? w.litlen[(i)] : HC12_LITLEN(i))
+#define HC12K_MLOFF(i)  (K ? w.mloff[(i)]  : HC12_MLOFF(i))
+#define HC12K_SET(i, pr, ll, mo) do { if (K) { const int k_ = (i); w.price[k_] = (pr); w.litlen[k_] = (ll); w.mloff[k_] = (mo); } else HC12_SET(i, pr, ll, mo); } while (0)
+struct Hc12InLds { static constexpr bool value = true; };
+struct Hc12Anywhere { static constexpr bool value = false; };
 #define HC12_SET(i, pr, ll, mo) do { const int i_ = (i); \
         if (i_ < w.nl) { w.price[i_] = (pr); w.litlen[i_] = (ll); w.mloff[i_] = (mo); } \
         else { w.gprice[i_ - w.nl] = (pr); w.glitlen[i_ - w.nl] = (ll); w.gmloff[i_ - w.nl] = (mo); } } while (0)
@@ -642,21 +668,23 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
             f_window(ip + cur);
             LV(int, p0); LV(int, ll0); LV(uint32_t, mo0);
             uint64_t need;
-            {
+            auto scan = [&](auto tag) {
+                constexpr bool K = decltype(tag)::value;
                 const int ipL = ip, fb = fBase, curL = cur, lastL = last;
                 LANES({
                     const int pos = fb + LANE, c = pos - ipL;
                     p0[I_] = 0; ll0[I_] = 0; mo0[I_] = 0;
                     int want = 0;
                     if (c >= curL && c < lastL && pos <= mflimit && fLen[I_] != 0) {
-                        p0[I_] = HC12_PRICE(c); ll0[I_] = HC12_LITLEN(c); mo0[I_] = HC12_MLOFF(c);
-                        const int p1 = HC12_PRICE(c + 1), p4 = HC12_PRICE(c + kMinMatch);
+                        p0[I_] = HC12K_PRICE(c); ll0[I_] = HC12K_LITLEN(c); mo0[I_] = HC12K_MLOFF(c);
+                        const int p1 = HC12K_PRICE(c + 1), p4 = HC12K_PRICE(c + kMinMatch);
                         want = !(p1 <= p0[I_] && p4 < p0[I_] + 3);                          // fullUpdate skip test, :1929-1931
                     }
                     ll0[I_] = (int)((uint32_t)ll0[I_] | ((uint32_t)want << 31));
                 })
                 need = BALLOT(ll0[I_] < 0);
-            }
+            };
+            if (last + 8 < w.nl) scan(Hc12InLds{}); else scan(Hc12Anywhere{});
             if (!need) { cur = fBase + 64 - ip; continue; }
             const int s = ctz64(need);
             const int c = fBase + s - ip;
@@ -670,9 +698,10 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
             const int mlenC = (int)(RL(mo0, s) >> 16);
             const int ll = (mlenC == 1) ? baseLit : 0;                                     // :1976-1982
             const int lastOld = last;
-            bool tookLast = false;
-            {
-                const int basePrice = (mlenC == 1) ? ((c > ll) ? UNI(HC12_PRICE(c - ll)) : 0) : priceC;
+            auto update = [&](auto tag) {
+                constexpr bool K = decltype(tag)::value;
+                bool tookLast = false;
+                const int basePrice = (mlenC == 1) ? ((c > ll) ? UNI(HC12K_PRICE(c - ll)) : 0) : priceC;
                 const int nmLen = nm.len; const uint32_t nmOff = (uint32_t)nm.off;
                 const int litBase = priceC - hc_lit_price(baseLit);
                 for (int t0 = 1; t0 <= nmLen; t0 += 64) {
@@ -684,12 +713,12 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                             const int pos = c + t;
                             if (t < kMinMatch) {                                           // literals after cur, :1958-1972
                                 const int pr = litBase + hc_lit_price(baseLit + t);
-                                if (pr < HC12_PRICE(pos)) HC12_SET(pos, pr, baseLit + t, 1u << 16);
+                                if (pr < HC12K_PRICE(pos)) HC12K_SET(pos, pr, baseLit + t, 1u << 16);
                             } else {                                                       // every length of the match, :1984-2008
                                 const int pr = basePrice + hc_seq_price(ll, t);
-                                if (pos > lastOld + kHcTrailing || pr <= HC12_PRICE(pos)) {
+                                if (pos > lastOld + kHcTrailing || pr <= HC12K_PRICE(pos)) {
                                     took[I_] = 1;
-                                    HC12_SET(pos, pr, ll, ((uint32_t)t << 16) | nmOff);
+                                    HC12K_SET(pos, pr, ll, ((uint32_t)t << 16) | nmOff);
                                 }
                             }
                         }
@@ -697,12 +726,13 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                     if (nmLen - t0 < 64) tookLast = RL(took, nmLen - t0) != 0;
                 }
                 if (tookLast && lastOld < c + nmLen) last = c + nmLen;
-            }
-            LDS_FENCE();
-            {   const int pl = UNI(HC12_PRICE(last)); const int lastL = last;              // :2011-2018
-                LANES({ if (LANE >= 1 && LANE <= kHcTrailing) HC12_SET(lastL + LANE, pl + hc_lit_price(LANE), LANE, 1u << 16); })
-            }
-            LDS_FENCE();
+                LDS_FENCE();
+                {   const int pl = UNI(HC12K_PRICE(last)); const int lastL = last;          // :2011-2018
+                    LANES({ if (LANE >= 1 && LANE <= kHcTrailing) HC12K_SET(lastL + LANE, pl + hc_lit_price(LANE), LANE, 1u << 16); })
+                }
+                LDS_FENCE();
+            };
+            if ((lastOld > c + nm.len ? lastOld : c + nm.len) + 8 < w.nl) update(Hc12InLds{}); else update(Hc12Anywhere{});
             cur = c + 1;
         }
         if (!direct) {                                                                     // :2022-2024

@@ -869,8 +869,8 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
     pl->perBlock = (size_t)pl->chainStride * 2 + (size_t)pl->chainStride * 4 + ((size_t)pl->chainStride + 8) * 4 + (size_t)kHcHashEntries * 4 + (size_t)pl->fStride * 8;
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
-    size_t budget = (freeB + c->h12Bytes) / 4;
-    if (budget > ((size_t)40 << 30)) budget = (size_t)40 << 30;
+    size_t budget = (freeB + c->h12Bytes) / 2;
+    if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
     int64_t grp = (int64_t)(budget / pl->perBlock);
     if (const char* v = getenv("PLZ4HIP_HC12_GROUP")) { const int gv = atoi(v); if (gv >= 1) grp = gv; }
     if (grp < 1) grp = 1;

@@ -127,7 +127,7 @@ struct H12Emu {
         nPad = ((n > 0 ? n : 0) + 1 + 1023) / 1024 * 1024;
         padded = (uint8_t*)calloc((size_t)(n > 0 ? n : 0) + 64, 1);
         if (n > 0) memcpy(padded, src, (size_t)n);
-        chain = (uint16_t*)malloc((size_t)nPad * 2);
+        chain = (uint16_t*)malloc((size_t)nPad * 2 + 64);
         rank = (uint32_t*)malloc((size_t)nPad * 4);
         listBase = (uint32_t*)malloc(((size_t)nPad + 8) * 4);
         memset(listBase, 0xEE, 32);
