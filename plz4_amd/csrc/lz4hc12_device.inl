@@ -298,8 +298,10 @@ struct Hc12Walk {
     // its hash ends the chain; what lies below it in the list belongs to another hash.
     DEVM void take(const uint32_t (&e)[8])
     {
-        nb = 8; listEnded = 0;
-        for (int j = 7; j >= 0; --j) if (!listEnded && (e[j] & kHc12First)) { nb = 8 - j; listEnded = 1; }
+        uint32_t firsts = 0;                              // bit j: e[j] is the first position of its hash
+        for (int j = 0; j < 8; ++j) firsts |= (e[j] >> 31) << j;
+        listEnded = firsts != 0;
+        nb = firsts ? 8 - (31 - __builtin_clz(firsts)) : 8;   // the entries down to the highest such one
         for (int k = 0; k < 8; ++k) b[k] = e[7 - k] & ~kHc12First;
         cursor -= 8u;
     }

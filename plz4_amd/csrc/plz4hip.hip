@@ -60,6 +60,7 @@ struct CodecArgs {
     uint8_t*        h12Ws;                                   // gridDim.x x kHc12WsGlobalBytes: the price table's overflow
     int32_t*        h12Err;                                  // set when a kernel gives up (spin guard)
     int             rawMode;                                 // parse kernel: 1 = raw LZ4 blocks (dstCap per block), 0 = frame records
+    int             h12Gather, h12Idle;                      // search kernel: lanes a phase / the queue waits for before its section runs
 };
 
 __device__ __forceinline__ int next_block(uint32_t* q)
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
             const uint64_t mP = __builtin_amdgcn_ballot_w64(L.phase == kPhPattern);
             const uint64_t mI = __builtin_amdgcn_ballot_w64(L.phase == kPhIdle || L.phase == kPhWait);
             const bool busy = (mF | mC | mS | mK | mP) != 0;
-            if (mI && (__builtin_popcountll(mI) >= 16 || !busy)) {
+            if (mI && (__builtin_popcountll(mI) >= a.h12Idle || !busy)) {
                 // (1) this wave's lower bound on the positions it holds or may still take: published BEFORE it takes new ones
                 const int q0 = H12_LD(ctl.qNext);
                 int m = h12_wave_min((L.phase != kPhIdle && L.phase != kPhDone) ? p : 0x7FFFFFFF);
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
                 const int cF = __builtin_popcountll(mF), cC = __builtin_popcountll(mC), cS = __builtin_popcountll(mS),
                           cK = __builtin_popcountll(mK), cP = __builtin_popcountll(mP);
                 int top = cF; top = cC > top ? cC : top; top = cS > top ? cS : top; top = cK > top ? cK : top; top = cP > top ? cP : top;
-                const int need = top < 12 ? top : 12;
+                const int need = top < a.h12Gather ? top : a.h12Gather;
                 if (cF && cF >= need) {
                     const bool fl = L.phase == kPhFilter;
                     if (__builtin_amdgcn_ballot_w64(fl && !L.is_near())) { if (fl && !L.is_near() && L.filter_trip<false>(t, sw)) finish(); }
@@ -914,6 +915,9 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         a.h12F = (Hc12F*)(c->d_h12 + pl.offF); a.h12FStride = pl.fStride;
         a.h12Ws = c->d_h12 + pl.offWs; a.h12Err = (int32_t*)(c->d_h12 + pl.offErr);
         a.rawMode = rawMode;
+        a.h12Gather = 12; a.h12Idle = 16;
+        if (const char* v = getenv("PLZ4HIP_HC12_GATHER")) a.h12Gather = atoi(v);
+        if (const char* v = getenv("PLZ4HIP_HC12_IDLE")) a.h12Idle = atoi(v);
         HIPCHK(c, hipMemsetAsync(a.h12Err, 0, 4, s));
         const int nGroups = (nb + pl.group - 1) / pl.group;
         const int per = (nb + nGroups - 1) / nGroups;                     // groups of equal size (<= pl.group)

@@ -135,3 +135,89 @@ def test_gpu_hc_config4_full_size(ref, orc):
         for s, r, k, o in zip(srcs, res, st, outs):
             assert int(k) == 0 and int(r) == s.size and np.array_equal(o, s)
     eng.close()
+
+
+# ---- level 12 in its three device phases (plz4_amd/csrc/lz4hc12_device.inl): chains + per-hash lists, F(p) per position, parser
+def test_emu_hc12_vs_reference(ref, orc, emu):
+    """The three phases back to back on the CPU == LZ4_compress_HC(level 12), incl. the parser's own search for positions the
+    search phase leaves out (nc) and price-table entries beyond the LDS part (nl)."""
+    cases = [("T", synth.text(70000)), ("Z", np.zeros(9000, np.uint8)), ("M", synth.make("M", 140000, 65536)[60000:])]
+    cases += [(n, c[:6000]) for n, c in corpus.twin_cases()[:2]]
+    cases += [c for c in corpus.small_cases() if c[1].size in (0, 5, 12, 13, 14, 40, 300, 4097)]
+    cases += [("S%d" % s, corpus.structured(30000, s)) for s in range(3)]
+    for name, src in cases:
+        for k, cap in enumerate((orc.bound(src.size), src.size, max(src.size // 3, 1))):
+            a, da = ref.compress_hc(src, cap, 12)
+            for nc, nl in (((0, 1024), (7, 40)) if k < 2 else ((0, 1024),)):
+                b, db = emu.compress_hc12(src, cap, nc, nl)
+                assert a == b and np.array_equal(da, db), (name, src.size, cap, nc, nl, a, b)
+
+
+def test_emu_hc12_search_as_the_kernel_runs_it(emu):
+    """Hc12Walk (lists, source window, phases: what k_hc12_search runs per lane) gives the plain chain walk's answer
+    (Hc12Lane == LZ4HC_FindLongerMatch) for every position."""
+    rng = np.random.default_rng(5)
+    cases = [synth.text(80000), np.zeros(9000, np.uint8), synth.make("M", 140000, 65536)[50000:], rng.integers(0, 4, 20000, dtype=np.uint8)]
+    for it in range(4):
+        parts, have, n = [], 0, int(rng.integers(1000, 25000))
+        while have < n:
+            pat = rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8)
+            parts += [np.tile(pat, int(rng.integers(1, 3000))), rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8)]
+            have += parts[-1].size + parts[-2].size
+        cases.append(np.concatenate(parts)[:n].copy())
+    for src in cases:
+        assert emu.hc12_search_check(src) == 0, src.size
+
+
+def test_emu_hc12_golden_digests(emu):
+    for b, blk in _golden_blocks():
+        if b["level"] == 12 and b["bsz"] <= (64 << 10):
+            r, c = emu.compress_hc12(blk, b["bsz"])
+            assert r == b["ret"] and (not r or sha(c) == b["comp_sha"]), (b["kind"], b["bsz"], b["index"])
+
+
+@pytest.mark.gpu
+def test_gpu_hc12_groups_and_streams(ref, orc, monkeypatch):
+    """Level 12 through the three-phase kernels: a call cut into several workspace groups gives the same records; and two HC
+    jobs enqueued on two streams of one ctx (they share the ctx's HC workspaces) do not disturb each other."""
+    import torch
+    from plz4_amd._native import Engine
+    bsz = 256 << 10
+    data = synth.make("M", 11 * bsz + 999, bsz)
+    srcs = [data[o:o + bsz] for o in range(0, data.size, bsz)]
+    want = []
+    for s in srcs:
+        n, c = ref.compress_hc(s, bsz, 12)
+        want.append(c[:n] if n else None)
+    monkeypatch.setenv("PLZ4HIP_HC12_GROUP", "4")
+    eng = Engine(0)
+    recs = eng.encode_records(srcs, bsz, True, level=12)
+    for s, w, r in zip(srcs, want, recs):
+        if w is None:
+            assert r[3] & 0x80 and np.array_equal(r[4:-4], s)
+        else:
+            assert not (r[3] & 0x80) and np.array_equal(r[4:-4], w)
+    # two streams, level 12 and level 9, same ctx
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(data).to(dev)
+    nblk = len(srcs)
+    stride = eng.stage_stride(bsz)
+    outs = []
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for st, lvl in zip(streams, (12, 9)):
+        stage = torch.zeros(nblk * stride, dtype=torch.uint8, device=dev)
+        lens = torch.zeros(nblk, dtype=torch.int32, device=dev)
+        eng.dev_encode_records(d_src.data_ptr(), data.size, bsz, True, stage.data_ptr(), lens.data_ptr(), st.cuda_stream, level=lvl)
+        outs.append((lvl, stage, lens))
+    torch.cuda.synchronize()
+    for lvl, stage, lens in outs:
+        h_stage = stage.cpu().numpy(); h_len = lens.cpu().numpy()
+        for i, s in enumerate(srcs):
+            rec = h_stage[i * stride:i * stride + int(h_len[i])]
+            n, c = ref.compress_hc(s, bsz, lvl)
+            if n:
+                assert not (rec[3] & 0x80) and np.array_equal(rec[4:-4], c[:n]), (lvl, i)
+            else:
+                assert rec[3] & 0x80 and np.array_equal(rec[4:-4], s), (lvl, i)
+    eng.close()
