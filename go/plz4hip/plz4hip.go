@@ -80,6 +80,14 @@ func newBatch(bufs [][]byte, useCap bool) *batch {
 	}
 	return b
 }
+// i32p: &v[0], or nil for an empty batch (the C ABI accepts nBlocks == 0; indexing an empty slice would panic).
+func i32p(v []C.int32_t) *C.int32_t {
+	if len(v) == 0 {
+		return nil
+	}
+	return &v[0]
+}
+
 func (b *batch) free() { b.pin.Unpin(); C.free(b.ptrs) }
 
 // CompressBatch == clz4.CompressFast(src[i], dst[i], 1) for every i (clz4.go:31-45).
@@ -89,7 +97,7 @@ func (c *Ctx) CompressBatch(src, dst [][]byte, level int) ([]int, error) {
 	defer s.free()
 	defer d.free()
 	res := make([]C.int32_t, len(src))
-	rc := C.plz4hip_compress_batch(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(d.ptrs), &d.lens[0], C.int(level), &res[0])
+	rc := C.plz4hip_compress_batch(c.p, C.int(len(src)), (*unsafe.Pointer)(s.ptrs), i32p(s.lens), (*unsafe.Pointer)(d.ptrs), i32p(d.lens), C.int(level), i32p(res))
 	if rc != C.PLZ4HIP_OK {
 		return nil, c.engineErr(rc)
 	}
@@ -106,7 +114,7 @@ func (c *Ctx) DecompressBatch(src, dst [][]byte) ([]int, error) {
 	defer s.free()
 	defer d.free()
 	res := make([]C.int32_t, len(src))
-	rc := C.plz4hip_decompress_batch(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(d.ptrs), &d.lens[0], &res[0])
+	rc := C.plz4hip_decompress_batch(c.p, C.int(len(src)), (*unsafe.Pointer)(s.ptrs), i32p(s.lens), (*unsafe.Pointer)(d.ptrs), i32p(d.lens), i32p(res))
 	if rc != C.PLZ4HIP_OK {
 		return nil, c.engineErr(rc)
 	}
@@ -127,7 +135,7 @@ func (c *Ctx) EncodeRecords(src, rec [][]byte, bsz, level int, blockChecksum boo
 	if blockChecksum {
 		bc = 1
 	}
-	rc := C.plz4hip_encode_records(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], C.int(bsz), C.int(level), bc, (**C.void)(r.ptrs), &res[0])
+	rc := C.plz4hip_encode_records(c.p, C.int(len(src)), (*unsafe.Pointer)(s.ptrs), i32p(s.lens), C.int(bsz), C.int(level), bc, (*unsafe.Pointer)(r.ptrs), i32p(res))
 	if rc != C.PLZ4HIP_OK {
 		return nil, c.engineErr(rc)
 	}
@@ -150,7 +158,7 @@ func (c *Ctx) DecodeRecords(rec, dst [][]byte, bsz int, blockChecksum bool) (n [
 	if blockChecksum {
 		bc = 1
 	}
-	rc := C.plz4hip_decode_records(c.p, C.int(len(rec)), (**C.void)(r.ptrs), &r.lens[0], C.int(bsz), bc, (**C.void)(d.ptrs), &res[0], &st[0])
+	rc := C.plz4hip_decode_records(c.p, C.int(len(rec)), (*unsafe.Pointer)(r.ptrs), i32p(r.lens), C.int(bsz), bc, (*unsafe.Pointer)(d.ptrs), i32p(res), i32p(st))
 	if rc != C.PLZ4HIP_OK {
 		return nil, nil, c.engineErr(rc)
 	}
@@ -205,7 +213,7 @@ func (c *Ctx) CompressBatchDict(src, dst [][]byte, level int, d *Dict) ([]int, e
 	defer s.free()
 	defer o.free()
 	res := make([]C.int32_t, len(src))
-	rc := C.plz4hip_compress_batch_dict(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(o.ptrs), &o.lens[0], C.int(level), d.ptr(), &res[0])
+	rc := C.plz4hip_compress_batch_dict(c.p, C.int(len(src)), (*unsafe.Pointer)(s.ptrs), i32p(s.lens), (*unsafe.Pointer)(o.ptrs), i32p(o.lens), C.int(level), d.ptr(), i32p(res))
 	if rc != C.PLZ4HIP_OK {
 		return nil, c.engineErr(rc)
 	}
@@ -222,7 +230,7 @@ func (c *Ctx) DecompressBatchDict(src, dst [][]byte, d *Dict) ([]int, error) {
 	defer s.free()
 	defer o.free()
 	res := make([]C.int32_t, len(src))
-	rc := C.plz4hip_decompress_batch_dict(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], (**C.void)(o.ptrs), &o.lens[0], d.ptr(), &res[0])
+	rc := C.plz4hip_decompress_batch_dict(c.p, C.int(len(src)), (*unsafe.Pointer)(s.ptrs), i32p(s.lens), (*unsafe.Pointer)(o.ptrs), i32p(o.lens), d.ptr(), i32p(res))
 	if rc != C.PLZ4HIP_OK {
 		return nil, c.engineErr(rc)
 	}
@@ -250,8 +258,8 @@ func (c *Ctx) EncodeRecordsEx(src, rec [][]byte, bsz, level int, blockChecksum, 
 			tp = unsafe.Pointer(&prevTail[0])
 		}
 	}
-	rc := C.plz4hip_encode_records_ex(c.p, C.int(len(src)), (**C.void)(s.ptrs), &s.lens[0], C.int(bsz), C.int(level), b2i(blockChecksum), b2i(linked),
-		d.ptr(), tp, tl, (**C.void)(r.ptrs), &res[0])
+	rc := C.plz4hip_encode_records_ex(c.p, C.int(len(src)), (*unsafe.Pointer)(s.ptrs), i32p(s.lens), C.int(bsz), C.int(level), b2i(blockChecksum), b2i(linked),
+		d.ptr(), tp, tl, (*unsafe.Pointer)(r.ptrs), i32p(res))
 	if rc != C.PLZ4HIP_OK {
 		return nil, c.engineErr(rc)
 	}
@@ -277,8 +285,8 @@ func (c *Ctx) DecodeRecordsEx(rec, dst [][]byte, bsz int, blockChecksum, linked 
 		wp = unsafe.Pointer(&window[0])
 		wl = C.int(*windowLen)
 	}
-	rc := C.plz4hip_decode_records_ex(c.p, C.int(len(rec)), (**C.void)(r.ptrs), &r.lens[0], C.int(bsz), b2i(blockChecksum), b2i(linked),
-		d.ptr(), wp, &wl, (**C.void)(o.ptrs), &res[0], &st[0])
+	rc := C.plz4hip_decode_records_ex(c.p, C.int(len(rec)), (*unsafe.Pointer)(r.ptrs), i32p(r.lens), C.int(bsz), b2i(blockChecksum), b2i(linked),
+		d.ptr(), wp, &wl, (*unsafe.Pointer)(o.ptrs), i32p(res), i32p(st))
 	if rc != C.PLZ4HIP_OK {
 		return nil, nil, c.engineErr(rc)
 	}
@@ -303,9 +311,9 @@ func (c *Ctx) DecodeRecordsChains(chainFirst []int32, rec, dst [][]byte, bsz int
 	res := make([]C.int32_t, len(rec)+1)
 	st := make([]C.int32_t, len(rec)+1)
 	nChains := len(chainFirst) - 1
-	rc := C.plz4hip_decode_records_chains(c.p, C.int(nChains), (*C.int32_t)(unsafe.Pointer(&chainFirst[0])), (**C.void)(r.ptrs), &r.lens[0],
+	rc := C.plz4hip_decode_records_chains(c.p, C.int(nChains), (*C.int32_t)(unsafe.Pointer(&chainFirst[0])), (*unsafe.Pointer)(r.ptrs), i32p(r.lens),
 		C.int(bsz), b2i(blockChecksum), unsafe.Pointer(&windows[0]), (*C.int32_t)(unsafe.Pointer(&windowLen[0])),
-		(**C.void)(o.ptrs), &res[0], &st[0])
+		(*unsafe.Pointer)(o.ptrs), i32p(res), i32p(st))
 	if rc != C.PLZ4HIP_OK {
 		return nil, nil, c.engineErr(rc)
 	}

@@ -18,8 +18,12 @@
  * turned into stored blocks by the caller.
  *
  * Plain C, pointers and sizes only.  Host-pointer entry points never retain caller memory after return.
- * Thread-safety: a ctx serialises its own calls with an internal mutex and calls hipSetDevice() on entry
- * (goroutines migrate between OS threads); use one ctx per writer/reader for concurrency.
+ * Thread-safety: a ctx serialises its own calls with an internal mutex; every entry point runs on the ctx's device and
+ * puts the calling thread's current HIP device back before it returns (goroutines migrate between OS threads); use one
+ * ctx per writer/reader for concurrency, one per device for several GPUs (section D).  plz4hip_last_error returns the
+ * calling thread's own copy of the text (valid until that thread asks again).
+ * Memory: the host-buffer calls keep their pinned host + device staging (up to 3 chunks of <= 2 GiB) and the HC levels their
+ * workspaces between calls; plz4hip_ctx_trim gives them back.
  */
 #ifndef PLZ4HIP_H
 #define PLZ4HIP_H
@@ -31,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PLZ4HIP_ABI_VERSION 1
+#define PLZ4HIP_ABI_VERSION 2
 
 enum {
     PLZ4HIP_OK            =  0,
@@ -56,6 +60,7 @@ int         plz4hip_device_count(void);                       /* <0: PLZ4HIP_E_D
 int         plz4hip_ctx_create(int device, plz4hip_ctx** out);
 void        plz4hip_ctx_destroy(plz4hip_ctx* ctx);
 const char* plz4hip_last_error(const plz4hip_ctx* ctx);       /* text of the last PLZ4HIP_E_* on this ctx */
+int         plz4hip_ctx_trim(plz4hip_ctx* ctx);                /* release staging buffers and HC workspaces (waits for work in flight) */
 
 /* == clz4.CompressBound (clz4.go:27-29) -> LZ4_compressBound (lz4.h:215).  Pure host arithmetic. */
 int plz4hip_compress_bound(int n);
@@ -182,9 +187,12 @@ int plz4hip_dev_decode_records(plz4hip_ctx* ctx, const void* body, const int64_t
                                int32_t* result, int32_t* status, void* stream);
 
 /* Raw LZ4 blocks on the device (no record framing): block i = src + i*srcStride (srcLen[i] bytes) ->
- * dst + i*dstStride (capacity dstCap[i]); result[i] as in A.  srcLen/dstCap/result are device arrays. */
+ * dst + i*dstStride (capacity dstCap[i]); result[i] as in A, levels 1..12.  srcLen/dstCap/result are device arrays; maxLen
+ * (host value, >= every srcLen[i]) sizes the HC workspace and is only read for levels 2..12.
+ * HC levels (here and in plz4hip_dev_encode_records) work in per-ctx workspaces: jobs enqueued on different streams of one ctx
+ * are ordered behind each other on the device (an event wait, no host block); they never overlap. */
 int plz4hip_dev_compress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
-                         void* dst, int64_t dstStride, const int32_t* dstCap, int level, int32_t* result, void* stream);
+                         void* dst, int64_t dstStride, const int32_t* dstCap, int level, int maxLen, int32_t* result, void* stream);
 int plz4hip_dev_decompress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
                            void* dst, int64_t dstStride, const int32_t* dstCap, int32_t* result, void* stream);
 

@@ -12,13 +12,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libplz4hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 SYMBOLS = [
     "plz4hip_abi_version", "plz4hip_device_count", "plz4hip_ctx_create", "plz4hip_ctx_destroy",
     "plz4hip_last_error", "plz4hip_compress_bound", "plz4hip_compress_batch", "plz4hip_decompress_batch",
     "plz4hip_xxh32_batch", "plz4hip_encode_records", "plz4hip_decode_records", "plz4hip_dev_stage_stride",
     "plz4hip_dev_encode_records", "plz4hip_dev_compact_records", "plz4hip_dev_scatter_records",
-    "plz4hip_dev_decode_records", "plz4hip_dev_compress", "plz4hip_dev_decompress",
+    "plz4hip_dev_decode_records", "plz4hip_dev_compress", "plz4hip_dev_decompress", "plz4hip_ctx_trim",
     "plz4hip_dev_resident_waves", "plz4hip_dict_create", "plz4hip_dict_destroy", "plz4hip_compress_batch_dict", "plz4hip_decode_records_chains",
     "plz4hip_decompress_batch_dict", "plz4hip_encode_records_ex", "plz4hip_decode_records_ex",
 ]
@@ -84,7 +84,7 @@ def load():
     L.plz4hip_dev_decode_records.restype = C.c_int
     L.plz4hip_dev_decode_records.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp, vp, vp]
     L.plz4hip_dev_compress.restype = C.c_int
-    L.plz4hip_dev_compress.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int, vp, vp]
+    L.plz4hip_dev_compress.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp]
     L.plz4hip_dev_decompress.restype = C.c_int
     L.plz4hip_dev_decompress.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp, vp, vp]
     L.plz4hip_dev_resident_waves.restype = C.c_int

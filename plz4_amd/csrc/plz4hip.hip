@@ -715,6 +715,7 @@ struct plz4hip_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
     std::mutex   mu;
+    std::mutex   errMu;                // guards err alone: argument checks report before `mu` is taken
     std::string  err;
     uint32_t*    d_queues = nullptr;   // ring of work-queue counters
     int          qslot = 0;
@@ -762,10 +763,19 @@ int fail(plz4hip_ctx* c, int code, const char* what, hipError_t e = hipSuccess)
         char buf[512];
         if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
         else snprintf(buf, sizeof buf, "%s", what);
+        std::lock_guard<std::mutex> g(c->errMu);
         c->err = buf;
     }
     return code;
 }
+
+// Entry points run on the ctx's device and leave the calling thread's current device as they found it.
+struct DeviceGuard {
+    int prev = -1; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) err = hipSetDevice(dev); else prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) hipSetDevice(prev); }
+};
+#define ENTER_DEVICE(ctx) DeviceGuard dg_((ctx)->device); HIPCHK((ctx), dg_.err)
 
 #define HIPCHK(ctx, call)                                                         \
     do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail((ctx), PLZ4HIP_E_DEVICE, #call, e_); } while (0)
@@ -983,7 +993,8 @@ int plz4hip_ctx_create(int device, plz4hip_ctx** out)
     plz4hip_ctx* c = new (std::nothrow) plz4hip_ctx();
     if (!c) return PLZ4HIP_E_NOMEM;
     c->device = device;
-    hipError_t e = hipSetDevice(device);
+    DeviceGuard dg(device);
+    hipError_t e = dg.err;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_queues, kQueueSlots * sizeof(uint32_t));
     if (e == hipSuccess) e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device);
@@ -1009,7 +1020,7 @@ int plz4hip_ctx_create(int device, plz4hip_ctx** out)
 void plz4hip_ctx_destroy(plz4hip_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
     if (c->d_queues) hipFree(c->d_queues);
     for (auto& sl : c->slot) {
@@ -1023,25 +1034,52 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     delete c;
 }
 
-const char* plz4hip_last_error(const plz4hip_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+// Give back what the host-buffer calls and the HC levels keep between calls: pinned host + device staging, HC workspaces.
+int plz4hip_ctx_trim(plz4hip_ctx* c)
+{
+    if (!c) return PLZ4HIP_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    ENTER_DEVICE(c);
+    if (c->hcPending) { HIPCHK(c, hipEventSynchronize(c->hcDone)); c->hcPending = false; }
+    for (auto& sl : c->slot) {
+        if (sl.s) HIPCHK(c, hipStreamSynchronize(sl.s));
+        if (sl.h) { hipHostFree(sl.h); sl.h = nullptr; sl.hcap = 0; }
+        if (sl.d) { hipFree(sl.d); sl.d = nullptr; sl.dcap = 0; }
+    }
+    if (c->d_hc) { hipFree(c->d_hc); c->d_hc = nullptr; c->hcWaves = 0; }
+    if (c->d_h12) { hipFree(c->d_h12); c->d_h12 = nullptr; c->h12Bytes = 0; }
+    return PLZ4HIP_OK;
+}
+
+const char* plz4hip_last_error(const plz4hip_ctx* c)
+{
+    if (!c) return "null ctx";
+    static thread_local std::string copy;          // the caller's own copy: valid until this thread asks again
+    std::lock_guard<std::mutex> g(const_cast<plz4hip_ctx*>(c)->errMu);
+    copy = c->err;
+    return copy.c_str();
+}
 
 int plz4hip_dev_resident_waves(plz4hip_ctx* c, int decode) { return c ? (decode ? c->decWaves : c->encWaves) : PLZ4HIP_E_ARG; }
 
 // ---------------------------------------------------------------------------------------- device-resident API
 int plz4hip_dev_compress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
-                         void* dst, int64_t dstStride, const int32_t* dstCap, int level, int32_t* result, void* stream)
+                         void* dst, int64_t dstStride, const int32_t* dstCap, int level, int maxLen, int32_t* result, void* stream)
 {
     if (!c || nBlocks < 0 || !srcLen || !dstCap || !result) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_compress: bad argument");
-    if (level != 1) return fail(c, PLZ4HIP_E_UNSUPPORTED, "only level 1 is built");
+    if (level != 1 && !is_hc_level(level)) return fail(c, PLZ4HIP_E_UNSUPPORTED, "levels 1..12 are built");
     if (nBlocks == 0) return PLZ4HIP_OK;
+    if (is_hc_level(level) && maxLen <= 0) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_compress: levels 2..12 need maxLen (the largest srcLen[i]; the lengths are on the device)");
     std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
     CodecArgs a{};
     a.src = (const uint8_t*)src; a.srcStride = srcStride; a.srcLen = srcLen;
     a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCap = dstCap;
-    a.result = result; a.queue = q; a.nBlocks = nBlocks;
+    a.result = result; a.nBlocks = nBlocks;
+    a.dictLen = -1; a.prevTailLen = -1;
+    if (is_hc_level(level)) { a.level = level; return launch_hc(c, s, a, nBlocks, maxLen, 1); }
+    hipError_t e; a.queue = next_queue(c, s, &e); HIPCHK(c, e);
     ENC_LAUNCH(k_encode_raw, nBlocks, c, s, a);
     HIPCHK(c, hipGetLastError());
     return PLZ4HIP_OK;
@@ -1053,13 +1091,14 @@ int plz4hip_dev_decompress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t
     if (!c || nBlocks < 0 || !srcLen || !dstCap || !result) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_decompress: bad argument");
     if (nBlocks == 0) return PLZ4HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
     CodecArgs a{};
     a.src = (const uint8_t*)src; a.srcStride = srcStride; a.srcLen = srcLen;
     a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCap = dstCap;
     a.result = result; a.queue = q; a.nBlocks = nBlocks;
+    a.dictLen = -1; a.prevTailLen = -1;
     hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
     HIPCHK(c, hipGetLastError());
     return PLZ4HIP_OK;
@@ -1075,7 +1114,7 @@ int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes
     const int nBlocks = (int)nb64;
     if (nBlocks == 0) return PLZ4HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     CodecArgs a{};
     a.src = (const uint8_t*)src; a.srcStride = bsz; a.srcBytes = srcBytes; a.bsz = bsz;
@@ -1102,7 +1141,7 @@ int plz4hip_dev_compact_records(plz4hip_ctx* c, const void* stage, int64_t stage
     if (body && bodyCap <= 0) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_compact_records: bodyCap");
     if (nBlocks == 0) return PLZ4HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, recLen, recOff, nBlocks);
     HIPCHK(c, hipGetLastError());
@@ -1120,7 +1159,7 @@ int plz4hip_dev_scatter_records(plz4hip_ctx* c, const void* src, const int64_t* 
     if (!c || n < 0 || !src || !srcOff || !len || !dstOff || !dst || maxLen < 0 || dstCap < 0) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_scatter_records: bad argument");
     if (n == 0) return PLZ4HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_move_records, dim3(n, move_slices(maxLen)), dim3(256), 0, s,
                        (const uint8_t*)src, srcOff, (int64_t)0, len, dstOff, (uint8_t*)dst, dstCap);
@@ -1135,13 +1174,14 @@ int plz4hip_dev_decode_records(plz4hip_ctx* c, const void* body, const int64_t* 
     if (!c || nBlocks < 0 || !body || !recOff || !dst || !result || !status || bsz <= 0) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_decode_records: bad argument");
     if (nBlocks == 0) return PLZ4HIP_OK;
     std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
     hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
     CodecArgs a{};
     a.src = (const uint8_t*)body; a.recOff = recOff; a.bsz = bsz;
     a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCapAll = dstCap;
     a.result = result; a.status = status; a.queue = q; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
+    a.dictLen = -1; a.prevTailLen = -1;
     hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
     HIPCHK(c, hipGetLastError());
     return PLZ4HIP_OK;
@@ -1201,7 +1241,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         if (oc > maxOut) maxOut = oc;
     }
     std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER_DEVICE(c);
     const bool dictMode = dj && dj->any;
     const bool hcMode = dj && is_hc_level(dj->level);
     // a linked DECODE is one serial chain (block i needs block i-1's output): one chunk.  A linked ENCODE needs only the
@@ -1210,7 +1250,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     const bool chained = dictMode && dj->linked && mode == 3;
     if (dictMode && dj->prevTail && dj->prevTailLen > 65536) return fail(c, PLZ4HIP_E_ARG, "prevTail longer than 64 KiB");
 
-    size_t kChunkBytes = (size_t)6 << 30;      // x kSlots in flight: enough blocks for every encoder wave slot at 4 MiB blocks
+    size_t kChunkBytes = (size_t)2 << 30;      // x kSlots in flight; pinned host + device staging stay allocated until plz4hip_ctx_trim / destroy
     if (const char* v = getenv("PLZ4HIP_HOST_CHUNK_MB")) { const long mb = atol(v); if (mb > 0) kChunkBytes = (size_t)mb << 20; }   // tests: force many chunks
     const size_t gap = (dictMode && (mode == 0 || mode == 2)) ? 65536 : 0;     // encoders with a dictionary / linked blocks: room for the external segment
     int cb = nBlocks;
@@ -1393,7 +1433,7 @@ int plz4hip_dict_create(plz4hip_ctx* c, const void* dict, int dictLen, plz4hip_d
 {
     if (!c || !out || dictLen < 0 || (dictLen && !dict)) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dict_create: bad argument");
     std::lock_guard<std::mutex> g(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
+    ENTER_DEVICE(c);
     plz4hip_dict* d = new (std::nothrow) plz4hip_dict();
     if (!d) return fail(c, PLZ4HIP_E_NOMEM, "plz4hip_dict");
     const uint8_t* p = (const uint8_t*)dict;
@@ -1420,7 +1460,7 @@ int plz4hip_dict_create(plz4hip_ctx* c, const void* dict, int dictLen, plz4hip_d
 void plz4hip_dict_destroy(plz4hip_ctx* c, plz4hip_dict* d)
 {
     if (!d) return;
-    if (c) hipSetDevice(c->device);
+    DeviceGuard dg(c ? c->device : 0);
     if (d->d_bytes) hipFree(d->d_bytes);
     if (d->d_table) hipFree(d->d_table);
     if (d->d_hc) hipFree(d->d_hc);
