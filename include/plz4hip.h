@@ -154,6 +154,27 @@ int plz4hip_decode_records_chains(plz4hip_ctx* ctx, int nChains, const int32_t* 
                                   void* windows, int32_t* windowLen, void* const* dst, int32_t* result, int32_t* status);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * B''. Streaming content checksum on the device: xxh32.XXHZero (internal/pkg/xxh32/xxh32zero.go:58-86 Write, :204-235 Sum32)
+ *    as the reference feeds it, block after block (async/hash.go:99-111, sync/writer.go:267-271, sync/reader.go:56).
+ *    XXH32 has no combine operator: the stream is one serial chain, so this is ONE wavefront that runs beside the codec kernels
+ *    (it is there to take the hash off the host's critical path, not to be fast: see DESIGN.md for its rate).
+ *    create / reset: empty stream, seed 0.  sum: Sum32 of what was written so far (the stream goes on after it).
+ *    update (host bytes) / dev_update (device bytes, enqueued on `stream` behind the stream's previous update).
+ *    plz4hip_ctx_set_content_hash(ctx, h): while set (NULL clears it), every plz4hip_encode_records[_ex] call also writes the
+ *    plaintext of its blocks, in block order, into h, and every plz4hip_decode_records[_ex] call the plaintext it produced
+ *    (blocks whose result is <= 0 contribute nothing; the caller stops at the first bad block anyway) -- without the
+ *    plaintext passing through the host again.  A stream is fed from one place at a time.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct plz4hip_xxh32_stream plz4hip_xxh32_stream;
+int  plz4hip_xxh32_stream_create(plz4hip_ctx* ctx, plz4hip_xxh32_stream** out);
+void plz4hip_xxh32_stream_destroy(plz4hip_ctx* ctx, plz4hip_xxh32_stream* h);
+int  plz4hip_xxh32_stream_reset(plz4hip_ctx* ctx, plz4hip_xxh32_stream* h);
+int  plz4hip_xxh32_stream_update(plz4hip_ctx* ctx, plz4hip_xxh32_stream* h, const void* data, int64_t n);
+int  plz4hip_dev_xxh32_stream_update(plz4hip_ctx* ctx, plz4hip_xxh32_stream* h, const void* devData, int64_t n, void* stream);
+int  plz4hip_xxh32_stream_sum(plz4hip_ctx* ctx, plz4hip_xxh32_stream* h, uint32_t* out);
+int  plz4hip_ctx_set_content_hash(plz4hip_ctx* ctx, plz4hip_xxh32_stream* h);
+
+/* ---------------------------------------------------------------------------------------------------------
  * C. Device-resident pipeline (bench.py, GPU-to-GPU producers).  Every pointer below is a DEVICE pointer
  *    on ctx's device; work is enqueued on `stream` (a hipStream_t; NULL is HIP's default/null stream, as for any
  *    hip*Async call) and the call returns without synchronising.  Layout:

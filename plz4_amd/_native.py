@@ -21,6 +21,8 @@ SYMBOLS = [
     "plz4hip_dev_decode_records", "plz4hip_dev_compress", "plz4hip_dev_decompress", "plz4hip_ctx_trim",
     "plz4hip_dev_resident_waves", "plz4hip_dict_create", "plz4hip_dict_destroy", "plz4hip_compress_batch_dict", "plz4hip_decode_records_chains",
     "plz4hip_decompress_batch_dict", "plz4hip_encode_records_ex", "plz4hip_decode_records_ex",
+    "plz4hip_xxh32_stream_create", "plz4hip_xxh32_stream_destroy", "plz4hip_xxh32_stream_reset", "plz4hip_xxh32_stream_update",
+    "plz4hip_dev_xxh32_stream_update", "plz4hip_xxh32_stream_sum", "plz4hip_ctx_set_content_hash",
 ]
 
 E_NAMES = {0: "OK", -1: "E_ARG", -2: "E_DEVICE", -3: "E_NOMEM", -4: "E_UNSUPPORTED"}
@@ -102,6 +104,22 @@ def load():
     L.plz4hip_encode_records_ex.argtypes = [vp, C.c_int, pp, i32p, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, pp, i32p]
     L.plz4hip_decode_records_ex.restype = C.c_int
     L.plz4hip_decode_records_ex.argtypes = [vp, C.c_int, pp, i32p, C.c_int, C.c_int, C.c_int, vp, vp, C.POINTER(C.c_int), pp, i32p, i32p]
+    L.plz4hip_xxh32_stream_create.restype = C.c_int
+    L.plz4hip_xxh32_stream_create.argtypes = [vp, C.POINTER(C.c_void_p)]
+    L.plz4hip_xxh32_stream_destroy.restype = None
+    L.plz4hip_xxh32_stream_destroy.argtypes = [vp, vp]
+    L.plz4hip_xxh32_stream_reset.restype = C.c_int
+    L.plz4hip_xxh32_stream_reset.argtypes = [vp, vp]
+    L.plz4hip_xxh32_stream_update.restype = C.c_int
+    L.plz4hip_xxh32_stream_update.argtypes = [vp, vp, vp, C.c_int64]
+    L.plz4hip_dev_xxh32_stream_update.restype = C.c_int
+    L.plz4hip_dev_xxh32_stream_update.argtypes = [vp, vp, vp, C.c_int64, vp]
+    L.plz4hip_xxh32_stream_sum.restype = C.c_int
+    L.plz4hip_xxh32_stream_sum.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+    L.plz4hip_ctx_set_content_hash.restype = C.c_int
+    L.plz4hip_ctx_set_content_hash.argtypes = [vp, vp]
+    L.plz4hip_ctx_trim.restype = C.c_int
+    L.plz4hip_ctx_trim.argtypes = [vp]
     if L.plz4hip_abi_version() != ABI_VERSION:
         raise ImportError("plz4_amd: libplz4hip.so ABI %d != binding %d" % (L.plz4hip_abi_version(), ABI_VERSION))
     _lib = L
@@ -286,3 +304,33 @@ class Engine:
 
     def stage_stride(self, bsz: int) -> int:
         return int(self.L.plz4hip_dev_stage_stride(bsz))
+
+    # ---- B''. streaming content checksum (xxh32.XXHZero) on the device
+    def hash_create(self):
+        h = C.c_void_p()
+        self._chk(self.L.plz4hip_xxh32_stream_create(self.h, C.byref(h)))
+        return h
+
+    def hash_destroy(self, h):
+        self.L.plz4hip_xxh32_stream_destroy(self.h, h)
+
+    def hash_reset(self, h):
+        self._chk(self.L.plz4hip_xxh32_stream_reset(self.h, h))
+
+    def hash_update(self, h, buf: np.ndarray):
+        buf = np.ascontiguousarray(buf)
+        self._chk(self.L.plz4hip_xxh32_stream_update(self.h, h, buf.ctypes.data if buf.size else None, buf.size))
+
+    def dev_hash_update(self, h, ptr, n, stream=0):
+        self._chk(self.L.plz4hip_dev_xxh32_stream_update(self.h, h, ptr, n, stream))
+
+    def hash_sum(self, h) -> int:
+        out = C.c_uint32()
+        self._chk(self.L.plz4hip_xxh32_stream_sum(self.h, h, C.byref(out)))
+        return int(out.value)
+
+    def set_content_hash(self, h):
+        self._chk(self.L.plz4hip_ctx_set_content_hash(self.h, h))
+
+    def trim(self):
+        self._chk(self.L.plz4hip_ctx_trim(self.h))

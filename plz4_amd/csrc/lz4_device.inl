@@ -109,6 +109,97 @@ DEV uint32_t wave_xxh32(const uint8_t* p, int n)
     return h;
 }
 
+
+// Streaming xxHash32, seed 0 (xxh32.XXHZero, internal/pkg/xxh32/xxh32zero.go:58-86 Write, :204-235 Sum32; fed in block order by
+// async/hash.go:99-111).  The state lives in device memory between calls; Write is what the wave does, Sum32 is finished by
+// whoever reads the state back (it does not disturb it).  There is no combine operator for XXH32: the four chains are strictly
+// sequential over the whole stream, so this is one wave with four busy lanes -- it runs beside the codec kernels, it is not a
+// throughput kernel.
+struct XxhStream { uint32_t v[4]; uint32_t totalLo, totalHi; uint32_t fill; uint8_t buf[16]; uint32_t pad; };
+
+DEV void wave_xxh32_stream_reset(XxhStream* st)
+{
+    LANES({
+        if (LANE < 4) st->v[LANE] = (LANE == 0) ? XP1 + XP2 : (LANE == 1) ? XP2 : (LANE == 2) ? 0u : 0u - XP1;
+        if (LANE == 4) { st->totalLo = 0; st->totalHi = 0; st->fill = 0; st->pad = 0; }
+        if (LANE >= 8 && LANE < 24) st->buf[LANE - 8] = 0;
+    })
+    WAVE_FENCE();
+}
+
+DEV void wave_xxh32_stream_update(XxhStream* st, const uint8_t* p, int64_t n)
+{
+    if (n <= 0) return;
+    WAVE_FENCE();
+    uint32_t fill = UNI(st->fill);
+    {   // total += n
+        const uint32_t lo = UNI(st->totalLo), hi = UNI(st->totalHi);
+        const uint64_t t = (((uint64_t)hi << 32) | lo) + (uint64_t)n;
+        LANES({ if (LANE == 0) { st->totalLo = (uint32_t)t; st->totalHi = (uint32_t)(t >> 32); } })
+    }
+    if ((int64_t)fill + n < 16) {                                  // still less than a stripe: keep the bytes (xxh32zero.go:64-69)
+        LANES({ if (LANE < (int)n) st->buf[fill + LANE] = p[LANE]; })
+        LANES({ if (LANE == 0) st->fill = fill + (uint32_t)n; })
+        WAVE_FENCE();
+        return;
+    }
+    LV(uint32_t, acc);
+    LANES({ acc[I_] = st->v[LANE & 3]; })
+    if (fill) {                                                    // complete the buffered stripe (:71-84)
+        const int take = 16 - (int)fill;
+        LANES({ if (LANE < take) st->buf[fill + LANE] = p[LANE]; })
+        WAVE_FENCE();
+        LANES({ if (LANE < 4) acc[I_] = rotl32(acc[I_] + ld32u(st->buf + 4 * LANE) * XP2, 13) * XP1; })
+        p += take; n -= take;
+    }
+    const int64_t stripes = n >> 4;
+    LANES({
+        if (LANE < 4) {
+            const uint8_t* q = p + 4 * LANE;
+            uint32_t a = acc[I_];
+            int64_t s = 0;
+            for (; s + 8 <= stripes; s += 8) {                     // 8 loads in flight per lane
+                const uint32_t x0 = ld32u(q), x1 = ld32u(q + 16), x2 = ld32u(q + 32), x3 = ld32u(q + 48);
+                const uint32_t x4 = ld32u(q + 64), x5 = ld32u(q + 80), x6 = ld32u(q + 96), x7 = ld32u(q + 112);
+                a = rotl32(a + x0 * XP2, 13) * XP1; a = rotl32(a + x1 * XP2, 13) * XP1;
+                a = rotl32(a + x2 * XP2, 13) * XP1; a = rotl32(a + x3 * XP2, 13) * XP1;
+                a = rotl32(a + x4 * XP2, 13) * XP1; a = rotl32(a + x5 * XP2, 13) * XP1;
+                a = rotl32(a + x6 * XP2, 13) * XP1; a = rotl32(a + x7 * XP2, 13) * XP1;
+                q += 128;
+            }
+            for (; s < stripes; ++s) { a = rotl32(a + ld32u(q) * XP2, 13) * XP1; q += 16; }
+            acc[I_] = a;
+        }
+    })
+    p += stripes << 4;
+    const int tail = (int)(n & 15);
+    LANES({
+        if (LANE < 4) st->v[LANE] = acc[I_];
+        if (LANE >= 8 && LANE - 8 < tail) st->buf[LANE - 8] = p[LANE - 8];
+        if (LANE == 4) st->fill = (uint32_t)tail;
+    })
+    WAVE_FENCE();
+}
+
+// XXHZero.Sum32 over a copy of the state (plain code: host side of the C ABI, and the tests)
+static inline uint32_t xxh32_stream_sum(const XxhStream& st)
+{
+    auto rol = [](uint32_t x, int r) { return (x << r) | (x >> (32 - r)); };
+    const uint32_t P1 = 2654435761u, P2 = 2246822519u, P3 = 3266489917u, P4 = 668265263u, P5 = 374761393u;
+    const uint64_t total = ((uint64_t)st.totalHi << 32) | st.totalLo;
+    uint32_t h = (uint32_t)total;
+    if (total >= 16) h += rol(st.v[0], 1) + rol(st.v[1], 7) + rol(st.v[2], 12) + rol(st.v[3], 18);
+    else h += P5;
+    uint32_t i = 0;
+    for (; i + 4 <= st.fill; i += 4) {
+        const uint32_t w = (uint32_t)st.buf[i] | ((uint32_t)st.buf[i + 1] << 8) | ((uint32_t)st.buf[i + 2] << 16) | ((uint32_t)st.buf[i + 3] << 24);
+        h = rol(h + w * P3, 17) * P4;
+    }
+    for (; i < st.fill; ++i) h = rol(h + (uint32_t)st.buf[i] * P5, 11) * P1;
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+
 // ------------------------------------------------------------------------------------------ encoder
 // Hash of the bytes at p (lz4.c:777-806, 64-bit little-endian build).
 template <bool U16> DEV uint32_t seq_hash(uint64_t seq8)

@@ -660,6 +660,18 @@ __global__ __launch_bounds__(64) void k_xxh32(const uint8_t* base, int64_t strid
     }
 }
 
+// Streaming content checksum (xxh32.XXHZero): one wave writes the buffers base + i*stride (lens[i] bytes each, or `single`
+// bytes at base when lens is null) into the stream state, in order.  lens may be a result array: entries <= 0 are skipped.
+__global__ __launch_bounds__(64) void k_xxh32_stream(XxhStream* st, const uint8_t* base, int64_t stride, const int32_t* lens, int n, int64_t single, int reset)
+{
+    if (reset) wave_xxh32_stream_reset(st);
+    if (!lens) { wave_xxh32_stream_update(st, base, single); return; }
+    for (int i = 0; i < n; ++i) {
+        const int len = plz4_readfirstlane(lens[i]);
+        if (len > 0) wave_xxh32_stream_update(st, base + (int64_t)i * stride, len);
+    }
+}
+
 // Exclusive prefix sum int32 -> int64, one workgroup.
 __global__ __launch_bounds__(1024) void k_scan(const int32_t* __restrict__ len, int64_t* __restrict__ off, int n)
 {
@@ -711,6 +723,7 @@ __global__ __launch_bounds__(256) void k_move_records(const uint8_t* __restrict_
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ context
+struct plz4hip_xxh32_stream;
 struct plz4hip_ctx {
     int          device = 0;
     hipStream_t  stream = nullptr;
@@ -722,7 +735,9 @@ struct plz4hip_ctx {
     int          cus = 0;
     int          encWaves = 0, decWaves = 0;
     // host-API staging (grown on demand): a ring of chunks in flight, each with pinned host memory, device memory and a stream
-    struct HostSlot { uint8_t* h = nullptr; size_t hcap = 0; uint8_t* d = nullptr; size_t dcap = 0; hipStream_t s = nullptr; };
+    struct HostSlot { uint8_t* h = nullptr; size_t hcap = 0; uint8_t* d = nullptr; size_t dcap = 0; hipStream_t s = nullptr;
+                      hipEvent_t evData = nullptr, evHash = nullptr; bool hashBusy = false; };
+    plz4hip_xxh32_stream* contentHash = nullptr;   // plz4hip_ctx_set_content_hash
     static constexpr int kSlots = 3;
     HostSlot     slot[kSlots];
     uint8_t*     d_hc = nullptr;   int hcWaves = 0;     // HC workspace, one slot per resident HC wave (allocated on first use)
@@ -731,9 +746,13 @@ struct plz4hip_ctx {
     // Both HC workspaces belong to one job at a time: the stream of the last HC job and an event recorded behind it; an HC
     // job on another stream waits for that event on the device (no host block).
     hipEvent_t   hcDone = nullptr; hipStream_t hcStream = nullptr; bool hcPending = false;
+    hipStream_t  hashStream = nullptr;   // the streaming content checksum runs here, beside the codec kernels
 };
 
 // == clz4.DictCtx (clz4.go:96-120): a private device copy of the last 64 KiB of the dictionary + the LZ4_loadDictSlow table.
+// == xxh32.XXHZero (xxh32zero.go:58-86, :204-235): the stream state in device memory + an event behind its last update
+struct plz4hip_xxh32_stream { XxhStream* d_state = nullptr; hipEvent_t done = nullptr; };
+
 struct plz4hip_dict {
     uint8_t*  d_bytes = nullptr;  int len = 0;      // len < 8: the dictionary is dropped by liblz4 (lz4.c:1613-1615)
     uint32_t* d_table = nullptr;
@@ -1025,12 +1044,15 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     if (c->d_queues) hipFree(c->d_queues);
     for (auto& sl : c->slot) {
         if (sl.s) { hipStreamSynchronize(sl.s); hipStreamDestroy(sl.s); }
+        if (sl.evData) hipEventDestroy(sl.evData);
+        if (sl.evHash) hipEventDestroy(sl.evHash);
         if (sl.h) hipHostFree(sl.h);
         if (sl.d) hipFree(sl.d);
     }
     if (c->d_hc) hipFree(c->d_hc);
     if (c->d_h12) hipFree(c->d_h12);
     if (c->hcDone) hipEventDestroy(c->hcDone);
+    if (c->hashStream) { hipStreamSynchronize(c->hashStream); hipStreamDestroy(c->hashStream); }
     delete c;
 }
 
@@ -1244,6 +1266,8 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     ENTER_DEVICE(c);
     const bool dictMode = dj && dj->any;
     const bool hcMode = dj && is_hc_level(dj->level);
+    plz4hip_xxh32_stream* const hash = (mode == 2 || (mode == 3 && !(dj && dj->nChains > 1))) ? c->contentHash : nullptr;
+    if (hash && !c->hashStream) HIPCHK(c, hipStreamCreateWithFlags(&c->hashStream, hipStreamNonBlocking));
     // a linked DECODE is one serial chain (block i needs block i-1's output): one chunk.  A linked ENCODE needs only the
     // previous block's source tail, which the caller's buffers hold: it is cut into chunks like any other call, the first
     // block of a later chunk getting the tail of the block before it as its prevTail.
@@ -1284,6 +1308,10 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         });
         HIPCHK(c, hipMemcpyAsync(sl.d, sl.h, st.offRes, hipMemcpyHostToDevice, s));                                   // srcLen, dstCap
         HIPCHK(c, hipMemcpyAsync(sl.d + st.offIn, sl.h + st.offIn, (size_t)nb * st.inStride, hipMemcpyHostToDevice, s));
+        if (hash && mode == 2) {
+            if (!sl.evData) HIPCHK(c, hipEventCreateWithFlags(&sl.evData, hipEventDisableTiming));
+            HIPCHK(c, hipEventRecord(sl.evData, s));
+        }
         hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
         CodecArgs a{};
         a.src = sl.d + st.offIn + st.gap; a.srcStride = st.inStride; a.srcLen = (const int32_t*)(sl.d + st.offA);
@@ -1339,6 +1367,21 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
                                    (const uint8_t*)a.src, a.srcStride, a.srcLen, (uint32_t*)a.result, nb, q); break;
         }
         HIPCHK(c, hipGetLastError());
+        if (hash && (mode == 2 || mode == 3)) {
+            // The content checksum of this chunk's plaintext, in block order, on the ctx's hash stream: it starts once the
+            // chunk's plaintext is on the device (encode: the copy in; decode: the decode kernel) and runs beside whatever the
+            // slot's stream does next; chunks follow each other on the hash stream.
+            if (!sl.evData) HIPCHK(c, hipEventCreateWithFlags(&sl.evData, hipEventDisableTiming));
+            if (!sl.evHash) HIPCHK(c, hipEventCreateWithFlags(&sl.evHash, hipEventDisableTiming));
+            if (mode == 3) HIPCHK(c, hipEventRecord(sl.evData, s));             // (encode: recorded right behind the copy in)
+            HIPCHK(c, hipStreamWaitEvent(c->hashStream, sl.evData, 0));
+            if (mode == 2) hipLaunchKernelGGL(k_xxh32_stream, dim3(1), dim3(64), 0, c->hashStream, hash->d_state, (const uint8_t*)a.src, a.srcStride, a.srcLen, nb, (int64_t)0, 0);
+            else           hipLaunchKernelGGL(k_xxh32_stream, dim3(1), dim3(64), 0, c->hashStream, hash->d_state, (const uint8_t*)a.dst, a.dstStride, (const int32_t*)a.result, nb, (int64_t)0, 0);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipEventRecord(sl.evHash, c->hashStream));
+            HIPCHK(c, hipEventRecord(hash->done, c->hashStream));
+            sl.hashBusy = true;
+        }
         if (mode != 4) {                                       // pack the outputs: sizes -> offsets -> back to back
             int32_t* dLen = (int32_t*)(sl.d + st.offLen); int64_t* dOff = (int64_t*)(sl.d + st.offOff);
             hipLaunchKernelGGL(k_out_len, dim3((nb + 255) / 256), dim3(256), 0, s, (const int32_t*)a.result, dLen, nb);
@@ -1358,6 +1401,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         plz4hip_ctx::HostSlot& sl = c->slot[k % nSlots];
         const int b0 = k * cb, nb = (nBlocks - b0 < cb) ? nBlocks - b0 : cb;
         HIPCHK(c, hipStreamSynchronize(sl.s));
+        if (sl.hashBusy) { HIPCHK(c, hipEventSynchronize(sl.evHash)); sl.hashBusy = false; }     // the slot's buffers are free again
         const int32_t* hRes = (const int32_t*)(sl.h + st.offRes);
         const int32_t* hSt  = (const int32_t*)(sl.h + st.offSt);
         const int32_t* hLen = (const int32_t*)(sl.h + st.offLen);
@@ -1426,6 +1470,105 @@ int plz4hip_decode_records(plz4hip_ctx* c, int nBlocks, const void* const* rec, 
     if (!c || nBlocks < 0 || bsz <= 0 || (nBlocks && (!rec || !recLen || !dst || !result || !status))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_decode_records: bad argument");
     for (int i = 0; i < nBlocks; ++i) if (recLen[i] < 4) return fail(c, PLZ4HIP_E_ARG, "record shorter than its size word");
     return host_codec(c, 3, nBlocks, rec, recLen, dst, nullptr, bsz, blockChecksum, result, status);
+}
+
+
+// ---------------------------------------------------------------------------------------- streaming content checksum
+int plz4hip_xxh32_stream_create(plz4hip_ctx* c, plz4hip_xxh32_stream** out)
+{
+    if (!c || !out) return fail(c, PLZ4HIP_E_ARG, "plz4hip_xxh32_stream_create: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    ENTER_DEVICE(c);
+    if (!c->hashStream) HIPCHK(c, hipStreamCreateWithFlags(&c->hashStream, hipStreamNonBlocking));
+    plz4hip_xxh32_stream* h = new (std::nothrow) plz4hip_xxh32_stream();
+    if (!h) return fail(c, PLZ4HIP_E_NOMEM, "plz4hip_xxh32_stream");
+    hipError_t e = hipMalloc((void**)&h->d_state, sizeof(XxhStream));
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->done, hipEventDisableTiming);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_xxh32_stream, dim3(1), dim3(64), 0, c->hashStream, h->d_state, (const uint8_t*)nullptr, (int64_t)0, (const int32_t*)nullptr, 0, (int64_t)0, 1);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipEventRecord(h->done, c->hashStream);
+    }
+    if (e != hipSuccess) { if (h->d_state) hipFree(h->d_state); if (h->done) hipEventDestroy(h->done); delete h; return fail(c, PLZ4HIP_E_DEVICE, "plz4hip_xxh32_stream_create", e); }
+    *out = h;
+    return PLZ4HIP_OK;
+}
+
+void plz4hip_xxh32_stream_destroy(plz4hip_ctx* c, plz4hip_xxh32_stream* h)
+{
+    if (!h) return;
+    DeviceGuard dg(c ? c->device : 0);
+    if (c) { std::lock_guard<std::mutex> g(c->mu); if (c->contentHash == h) c->contentHash = nullptr; }
+    if (h->done) { hipEventSynchronize(h->done); hipEventDestroy(h->done); }
+    if (h->d_state) hipFree(h->d_state);
+    delete h;
+}
+
+int plz4hip_xxh32_stream_reset(plz4hip_ctx* c, plz4hip_xxh32_stream* h)
+{
+    if (!c || !h) return fail(c, PLZ4HIP_E_ARG, "plz4hip_xxh32_stream_reset: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    ENTER_DEVICE(c);
+    hipLaunchKernelGGL(k_xxh32_stream, dim3(1), dim3(64), 0, c->hashStream, h->d_state, (const uint8_t*)nullptr, (int64_t)0, (const int32_t*)nullptr, 0, (int64_t)0, 1);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(h->done, c->hashStream));
+    return PLZ4HIP_OK;
+}
+
+int plz4hip_dev_xxh32_stream_update(plz4hip_ctx* c, plz4hip_xxh32_stream* h, const void* data, int64_t n, void* stream)
+{
+    if (!c || !h || n < 0 || (n && !data)) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_xxh32_stream_update: bad argument");
+    if (n == 0) return PLZ4HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    ENTER_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(c, hipStreamWaitEvent(s, h->done, 0));                       // behind the last update, whichever stream it ran on
+    hipLaunchKernelGGL(k_xxh32_stream, dim3(1), dim3(64), 0, s, h->d_state, (const uint8_t*)data, (int64_t)0, (const int32_t*)nullptr, 0, n, 0);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(h->done, s));
+    return PLZ4HIP_OK;
+}
+
+int plz4hip_xxh32_stream_update(plz4hip_ctx* c, plz4hip_xxh32_stream* h, const void* data, int64_t n)
+{
+    if (!c || !h || n < 0 || (n && !data)) return fail(c, PLZ4HIP_E_ARG, "plz4hip_xxh32_stream_update: bad argument");
+    if (n == 0) return PLZ4HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    ENTER_DEVICE(c);
+    const size_t piece = (size_t)64 << 20;
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, (size_t)n < piece ? (size_t)n : piece));
+    int rc = PLZ4HIP_OK;
+    for (int64_t o = 0; o < n && rc == PLZ4HIP_OK; o += (int64_t)piece) {
+        const size_t k = (size_t)(n - o) < piece ? (size_t)(n - o) : piece;
+        hipError_t e = hipMemcpyAsync(d, (const uint8_t*)data + o, k, hipMemcpyHostToDevice, c->hashStream);
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_xxh32_stream, dim3(1), dim3(64), 0, c->hashStream, h->d_state, (const uint8_t*)d, (int64_t)0, (const int32_t*)nullptr, 0, (int64_t)k, 0); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->hashStream);
+        if (e != hipSuccess) rc = fail(c, PLZ4HIP_E_DEVICE, "plz4hip_xxh32_stream_update", e);
+    }
+    hipFree(d);
+    if (rc == PLZ4HIP_OK) HIPCHK(c, hipEventRecord(h->done, c->hashStream));
+    return rc;
+}
+
+int plz4hip_xxh32_stream_sum(plz4hip_ctx* c, plz4hip_xxh32_stream* h, uint32_t* out)
+{
+    if (!c || !h || !out) return fail(c, PLZ4HIP_E_ARG, "plz4hip_xxh32_stream_sum: bad argument");
+    std::lock_guard<std::mutex> g(c->mu);
+    ENTER_DEVICE(c);
+    HIPCHK(c, hipEventSynchronize(h->done));
+    XxhStream st;
+    HIPCHK(c, hipMemcpy(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost));
+    *out = xxh32_stream_sum(st);
+    return PLZ4HIP_OK;
+}
+
+int plz4hip_ctx_set_content_hash(plz4hip_ctx* c, plz4hip_xxh32_stream* h)
+{
+    if (!c) return PLZ4HIP_E_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->contentHash = h;
+    return PLZ4HIP_OK;
 }
 
 // ---------------------------------------------------------------------------------------- dictionaries / linked blocks

@@ -36,6 +36,15 @@ int emu_decode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
 
 uint32_t emu_xxh32(const uint8_t* p, int n) { return plz4::wave_xxh32(p, n); }
 
+// streaming content checksum: the pieces of `p` (piece k = lens[k] bytes) written one after the other, then Sum32
+uint32_t emu_xxh32_stream(const uint8_t* p, const int* lens, int nPieces)
+{
+    plz4::XxhStream st;
+    plz4::wave_xxh32_stream_reset(&st);
+    for (int k = 0; k < nPieces; ++k) { plz4::wave_xxh32_stream_update(&st, p, lens[k]); p += lens[k]; }
+    return plz4::xxh32_stream_sum(st);
+}
+
 int emu_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level)
 {
     static thread_local uint8_t* ws = nullptr;
