@@ -22,7 +22,7 @@
  * puts the calling thread's current HIP device back before it returns (goroutines migrate between OS threads); use one
  * ctx per writer/reader for concurrency, one per device for several GPUs (section D).  plz4hip_last_error returns the
  * calling thread's own copy of the text (valid until that thread asks again).
- * Memory: the host-buffer calls keep their pinned host + device staging (up to 3 chunks of <= 2 GiB) and the HC levels their
+ * Memory: the host-buffer calls keep their pinned host + device staging (up to 3 chunks of <= 4 GiB) and the HC levels their
  * workspaces between calls; plz4hip_ctx_trim gives them back.
  */
 #ifndef PLZ4HIP_H

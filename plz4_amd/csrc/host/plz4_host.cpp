@@ -140,6 +140,10 @@ struct HipEngine : BlockEngine {
     int DecodeRecordsEx(int n, const void* const* rec, const int32_t* rl_, int bsz, int bc, int linked, void* dict, void* win, int* wl,
                         void* const* d, int32_t* r, int32_t* st) override
     { return plz4hip_decode_records_ex(ctx, n, rec, rl_, bsz, bc, linked, (plz4hip_dict*)dict, win, wl, d, r, st); }
+    void* HashNew() override { plz4hip_xxh32_stream* h = nullptr; return plz4hip_xxh32_stream_create(ctx, &h) == 0 ? h : nullptr; }
+    void  HashFree(void* h) override { plz4hip_xxh32_stream_destroy(ctx, (plz4hip_xxh32_stream*)h); }
+    int   HashAttach(void* h) override { return plz4hip_ctx_set_content_hash(ctx, (plz4hip_xxh32_stream*)h); }
+    int   HashSum(void* h, uint32_t* out) override { return plz4hip_xxh32_stream_sum(ctx, (plz4hip_xxh32_stream*)h, out); }
 };
 struct VtEngine : BlockEngine {
     EngineVTable vt;
@@ -181,8 +185,19 @@ class WriterImpl : public Writer {
     Sink& wr; BlockEngine& eng; Options o;
     const int  bsz;
     const bool sync;                         // NParallel == 0 (sync/writer.go); else async/writer.go semantics
-    Bytes cur; size_t curLen = 0;            // srcBlk / srcOff
-    std::deque<Bytes> queue;                 // blocks handed to the "workers", not yet emitted
+    // A source block handed to the "workers", not yet emitted: its bytes are either the writer's own (a pooled buffer) or,
+    // inside one Write call, still the caller's (full blocks of a large Write are encoded straight from the caller's memory;
+    // what has not been drained when Write returns is copied, io.Writer must not keep p).
+    struct Blk { const uint8_t* p = nullptr; size_t n = 0; uint8_t* own = nullptr; };
+    std::vector<uint8_t*> pool;              // free block buffers (bsz bytes each, never zero-filled)
+    uint8_t* cur = nullptr; size_t curLen = 0;   // srcBlk / srcOff
+    std::deque<Blk> queue;
+    uint8_t* recArena = nullptr; size_t recArenaBlocks = 0;   // record buffers of a batch, reused
+    void* devHash = nullptr;                 // the engine's content-checksum stream (null: hash on the host)
+    uint8_t* getBuf() { if (!pool.empty()) { uint8_t* b = pool.back(); pool.pop_back(); return b; } return (uint8_t*)malloc((size_t)bsz); }
+    void putBuf(uint8_t* b) { if (b) pool.push_back(b); }
+    void clearQueue() { for (auto& b : queue) putBuf(b.own); queue.clear(); }
+    void ownQueue() { for (auto& b : queue) if (!b.own) { b.own = getBuf(); memcpy(b.own, b.p, b.n); b.p = b.own; } }
     bool headerDone = false, kicked = false, closed = false, reported = false;
     Error state;                                            // first error wins (async/writer.go:552-555)
     int64_t srcMark = 0, dstMark = 0;
@@ -194,6 +209,7 @@ class WriterImpl : public Writer {
     Error encode(int n, const void* const* src, const int32_t* len, void* const* rec, int32_t* rlen)
     {
         int rc;
+        struct Attach { BlockEngine& e; void* h; Attach(BlockEngine& e_, void* h_) : e(e_), h(h_) { if (h) e.HashAttach(h); } ~Attach() { if (h) e.HashAttach(nullptr); } } at(eng, devHash);
         if (!exMode()) rc = eng.EncodeRecords(n, src, len, bsz, o.Level, o.BlockChecksum ? 1 : 0, rec, rlen);
         else {
             if (o.HasDictionary && !dictTried) { dictTried = true; dictH = eng.DictCreate(o.Dictionary.data(), (int)o.Dictionary.size()); if (!dictH) return E(ErrUnsupported); }
@@ -230,9 +246,12 @@ class WriterImpl : public Writer {
         if (!headerDone) if (Error e = writeHeader()) return e;
         const int n = (int)queue.size();
         std::vector<const void*> src(n); std::vector<int32_t> len(n), rlen(n); std::vector<void*> rec(n);
-        std::vector<Bytes> recs(n);
-        for (int i = 0; i < n; i++) { src[i] = queue[i].data(); len[i] = (int32_t)queue[i].size(); recs[i].resize((size_t)bsz + 8); rec[i] = recs[i].data(); }
-        if (Error ee = encode(n, src.data(), len.data(), rec.data(), rlen.data())) { queue.clear(); return ee; }
+        const size_t recStride = (size_t)bsz + 8;
+        if ((size_t)n > recArenaBlocks) { free(recArena); recArena = (uint8_t*)malloc((size_t)n * recStride); recArenaBlocks = recArena ? (size_t)n : 0; if (!recArena) { clearQueue(); return E(ErrEngine); } }
+        struct RecView { uint8_t* p; uint8_t& operator[](size_t i) const { return p[i]; } uint8_t* data() const { return p; } };
+        std::vector<RecView> recs(n);
+        for (int i = 0; i < n; i++) { src[i] = queue[i].p; len[i] = (int32_t)queue[i].n; recs[i].p = recArena + (size_t)i * recStride; rec[i] = recs[i].p; }
+        if (Error ee = encode(n, src.data(), len.data(), rec.data(), rlen.data())) { clearQueue(); return ee; }
         Error err;
         // linkedCompressorHC.Compress hands liblz4's "does not fit" back WITHOUT joining zerr.ErrCompress
         // (compress/linked.go:47-49, unlike every other compressor), so CompressToBlk does not fall back to a stored block
@@ -246,10 +265,16 @@ class WriterImpl : public Writer {
             srcMark += len[i]; dstMark += (int64_t)w;
             if (e) err = e;
         }
-        queue.clear();
+        clearQueue();
         return err;
     }
-    void enqueue(Bytes&& b) { if (hashing) hasher.Write(b.data(), b.size()); queue.push_back(std::move(b)); kicked = true; }
+    void enqueue(const uint8_t* p, size_t n, uint8_t* own)
+    {
+        if (hashing && !devHash) hasher.Write(p, n);
+        Blk b; b.p = p; b.n = n; b.own = own;
+        queue.push_back(b); kicked = true;
+    }
+    void enqueueCur() { enqueue(cur, curLen, cur); cur = nullptr; curLen = 0; }
     Error maybeDrain(bool force) { if (force || (int)queue.size() >= batch_depth(o)) return drain(); return Error(); }
     Error latch(Error e) { if (e && !state) state = e; return state; }
     Error report() { if (state) reported = true; return state; }
@@ -257,16 +282,29 @@ class WriterImpl : public Writer {
     {
         uint8_t t[8] = {0};
         size_t n = 4;
-        if (hashing) { if (hasher.total == 0) hasher.Reset(); put32(t + 4, hasher.Sum32()); n = 8; }
+        if (hashing) {
+            uint32_t sum = 0;
+            if (devHash) { if (eng.HashSum(devHash, &sum) != 0) return E(ErrEngine); }
+            else { if (hasher.total == 0) hasher.Reset(); sum = hasher.Sum32(); }
+            put32(t + 4, sum); n = 8;
+        }
         return sinkWrite(t, n, nullptr);
     }
 
 public:
-    ~WriterImpl() override { if (dictH) eng.DictDestroy(dictH); }
+    ~WriterImpl() override
+    {
+        if (dictH) eng.DictDestroy(dictH);
+        if (devHash) eng.HashFree(devHash);
+        clearQueue(); putBuf(cur);
+        for (uint8_t* b : pool) free(b);
+        free(recArena);
+    }
     WriterImpl(Sink& w, BlockEngine& e, const Options& op)
         : wr(w), eng(e), o(op), bsz(BlockIdxSize(op.BlockSizeIdx)), sync(op.NParallel == 0 && !op.BlockLinked), hashing(op.ContentChecksum)
     {
         hasher.Reset();                                      // linked => async (plz4_writer.go:44-46)
+        if (hashing) devHash = eng.HashNew();                // the engine keeps the content checksum if it can (async/hash.go:99-111)
         if (!sync && o.HasContentSz && (int)(o.ContentSz / (uint64_t)bsz) + 1 > 1) kicked = true;   // async/writer.go:70-76
     }
     Error Write(const uint8_t* p, size_t n, size_t* consumed) override
@@ -276,16 +314,23 @@ public:
         if (state) return report();
         if (sync && !headerDone) { if (latch(writeHeader())) return report(); }            // sync/writer.go:64-68
         while (n > 0 && !state) {
-            if (cur.empty()) cur.resize((size_t)bsz);
+            if (curLen == 0 && n >= (size_t)bsz) {                                         // a full block straight from the caller
+                enqueue(p, (size_t)bsz, nullptr);
+                p += bsz; n -= (size_t)bsz; used += (size_t)bsz;
+                latch(maybeDrain(false));
+                continue;
+            }
+            if (!cur) cur = getBuf();
             const size_t k = std::min(n, (size_t)bsz - curLen);
-            memcpy(cur.data() + curLen, p, k);
+            memcpy(cur + curLen, p, k);
             curLen += k; p += k; n -= k; used += k;
             if (curLen == (size_t)bsz) {
-                enqueue(std::move(cur)); cur.clear(); curLen = 0;
+                enqueueCur();
                 latch(maybeDrain(false));
             }
         }
         if (sync && !state) latch(drain());                                                // the sync writer emits before returning
+        ownQueue();                                                                        // nothing of p is kept past this call
         if (consumed) *consumed = used;
         return report();
     }
@@ -296,12 +341,12 @@ public:
         if (state) return report();
         if (sync && !headerDone) { if (latch(writeHeader())) return report(); }
         while (!state) {
-            if (cur.empty()) cur.resize((size_t)bsz);
+            if (!cur) cur = getBuf();
             size_t got = 0;
-            Error e = r.read(cur.data() + curLen, (size_t)bsz - curLen, &got);
+            Error e = r.read(cur + curLen, (size_t)bsz - curLen, &got);
             curLen += got; used += (int64_t)got;
             if (e && e.code != ErrEOF) { latch(e); break; }
-            if (curLen == (size_t)bsz) { enqueue(std::move(cur)); cur.clear(); curLen = 0; latch(maybeDrain(false)); continue; }
+            if (curLen == (size_t)bsz) { enqueueCur(); latch(maybeDrain(false)); continue; }
             if (got == 0 || e.code == ErrEOF) break;                                       // io.EOF: leave the partial block cached
         }
         if (sync && !state) latch(drain());
@@ -311,7 +356,7 @@ public:
     Error Flush() override
     {
         if (state) return report();
-        if (curLen) { cur.resize(curLen); enqueue(std::move(cur)); cur.clear(); curLen = 0; }
+        if (curLen) enqueueCur();
         latch(drain());
         return report();
     }
@@ -322,8 +367,8 @@ public:
         Error err;
         if (sync) {                                                                         // sync/writer.go:133-186
             if (!headerDone) err = writeHeader();
-            else if (curLen) { cur.resize(curLen); enqueue(std::move(cur)); cur.clear(); curLen = 0; err = drain(); }
-            cur.clear(); curLen = 0;
+            else if (curLen) { enqueueCur(); err = drain(); }
+            curLen = 0;
             if (state) return Error();                     // Close succeeds in an error state but writes no trailer
             if (err) { state = err; return err; }
             progress(srcMark, dstMark);
@@ -337,8 +382,7 @@ public:
                 // nothing was ever written: the async writer emits nothing at all
             } else if (!kicked) {
                 // one sub-block payload closed before the pipeline started: _writeSync shortcut
-                cur.resize(curLen);
-                Bytes only = std::move(cur); cur.clear(); curLen = 0;
+                Bytes only(cur, cur + curLen); putBuf(cur); cur = nullptr; curLen = 0;
                 Error e = supported();
                 if (!e) e = writeHeader();
                 const int64_t hdrSz = dstMark;
@@ -350,13 +394,13 @@ public:
                     if (!e) e = sinkWrite(rec.data(), (size_t)rl_, nullptr);
                     if (!e) {
                         progress(0, hdrSz);
-                        if (hashing) { hasher.Reset(); hasher.total = 0; hasher.Write(only.data(), only.size()); }
+                        if (hashing && !devHash) { hasher.Reset(); hasher.total = 0; hasher.Write(only.data(), only.size()); }
                         e = trailer();
                     }
                 }
                 latch(e);
             } else {
-                if (curLen) { cur.resize(curLen); enqueue(std::move(cur)); cur.clear(); curLen = 0; }
+                if (curLen) enqueueCur();
                 Error e = drain();
                 if (!e && !headerDone) e = writeHeader();
                 if (!e) { progress(srcMark, dstMark); e = trailer(); }

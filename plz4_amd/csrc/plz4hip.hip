@@ -1274,7 +1274,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     const bool chained = dictMode && dj->linked && mode == 3;
     if (dictMode && dj->prevTail && dj->prevTailLen > 65536) return fail(c, PLZ4HIP_E_ARG, "prevTail longer than 64 KiB");
 
-    size_t kChunkBytes = (size_t)2 << 30;      // x kSlots in flight; pinned host + device staging stay allocated until plz4hip_ctx_trim / destroy
+    size_t kChunkBytes = (size_t)4 << 30;      // x kSlots in flight (smaller chunks starve the encoder's wave slots); pinned host + device staging stay allocated until plz4hip_ctx_trim / destroy
     if (const char* v = getenv("PLZ4HIP_HOST_CHUNK_MB")) { const long mb = atol(v); if (mb > 0) kChunkBytes = (size_t)mb << 20; }   // tests: force many chunks
     const size_t gap = (dictMode && (mode == 0 || mode == 2)) ? 65536 : 0;     // encoders with a dictionary / linked blocks: room for the external segment
     int cb = nBlocks;
