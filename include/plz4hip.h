@@ -220,6 +220,45 @@ int plz4hip_dev_decompress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64
 /* Number of waves the encode / decode kernels keep resident on ctx's device (for sizing batches). */
 int plz4hip_dev_resident_waves(plz4hip_ctx* ctx, int decode);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * D. Several GPUs of one node behind one handle (BASELINE.json north_star: independent blocks shard round-robin).
+ *    The reference spreads the blocks of a stream over NParallel worker goroutines and emits their records in order
+ *    (async/writer.go:232-282 compressLoop, :284-381 writeLoop, :439-467 kickoffAsync); here the workers are the GPUs:
+ *    block i of a call belongs to device i mod G, G = the number of entries passed to plz4hip_mgpu_create (one plz4hip_ctx
+ *    each; the same device may be listed more than once).  Results come back in block order; value semantics as in A / B.
+ *    Host buffers (what the cgo shim binds): one host thread per device drives that device's ctx.
+ *    Device-resident shards (GPU producers, bench): shard k is ONE buffer on device k holding blocks k, k+G, ... back to back.
+ *      dev_encode_frame: every device encodes + compacts its shard; record sizes go to the host, one prefix sum gives the
+ *        frame offsets (recOff, host, nBlocks+1 entries), and the frame body is assembled on device `owner` (an index into
+ *        the handle's devices): the other devices' records arrive peer to peer in pieces of <= 256 MiB through two scratch
+ *        buffers and are moved to their place while the next piece travels -- the owner holds the body + two pieces.
+ *      dev_decode_frame: the reverse: records are dealt from `owner` to the devices, each decodes its shard into shardDst[k]
+ *        (block j of shard k at shardDst[k] + j*dstStride).
+ *    Linked decode does not shard (one serial chain per frame): use plz4hip_decode_records_chains per device.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct plz4hip_mgpu plz4hip_mgpu;
+int          plz4hip_mgpu_create(const int* devices, int nDevices, plz4hip_mgpu** out);
+void         plz4hip_mgpu_destroy(plz4hip_mgpu* m);
+int          plz4hip_mgpu_count(const plz4hip_mgpu* m);
+plz4hip_ctx* plz4hip_mgpu_ctx(plz4hip_mgpu* m, int k);                /* the k-th device's ctx (dictionaries, trims, ...) */
+const char*  plz4hip_mgpu_last_error(const plz4hip_mgpu* m);
+
+int plz4hip_mgpu_compress_batch(plz4hip_mgpu* m, int nBlocks, const void* const* src, const int32_t* srcLen,
+                                void* const* dst, const int32_t* dstCap, int level, int32_t* result);
+int plz4hip_mgpu_decompress_batch(plz4hip_mgpu* m, int nBlocks, const void* const* src, const int32_t* srcLen,
+                                  void* const* dst, const int32_t* dstCap, int32_t* result);
+int plz4hip_mgpu_encode_records(plz4hip_mgpu* m, int nBlocks, const void* const* src, const int32_t* srcLen,
+                                int bsz, int level, int blockChecksum, void* const* rec, int32_t* recLen);
+int plz4hip_mgpu_decode_records(plz4hip_mgpu* m, int nBlocks, const void* const* rec, const int32_t* recLen,
+                                int bsz, int blockChecksum, void* const* dst, int32_t* result, int32_t* status);
+
+int plz4hip_mgpu_dev_encode_frame(plz4hip_mgpu* m, int nBlocks, const void* const* shardSrc, const int64_t* shardBytes,
+                                  int bsz, int level, int blockChecksum, int owner, void* body, int64_t bodyCap,
+                                  int64_t* recOff, int64_t* bodyBytes);
+int plz4hip_mgpu_dev_decode_frame(plz4hip_mgpu* m, int nBlocks, int owner, const void* body, const int64_t* recOff,
+                                  int bsz, int blockChecksum, void* const* shardDst, int64_t dstStride, int dstCap,
+                                  int32_t* result, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

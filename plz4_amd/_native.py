@@ -23,6 +23,9 @@ SYMBOLS = [
     "plz4hip_decompress_batch_dict", "plz4hip_encode_records_ex", "plz4hip_decode_records_ex",
     "plz4hip_xxh32_stream_create", "plz4hip_xxh32_stream_destroy", "plz4hip_xxh32_stream_reset", "plz4hip_xxh32_stream_update",
     "plz4hip_dev_xxh32_stream_update", "plz4hip_xxh32_stream_sum", "plz4hip_ctx_set_content_hash",
+    "plz4hip_mgpu_create", "plz4hip_mgpu_destroy", "plz4hip_mgpu_count", "plz4hip_mgpu_ctx", "plz4hip_mgpu_last_error",
+    "plz4hip_mgpu_compress_batch", "plz4hip_mgpu_decompress_batch", "plz4hip_mgpu_encode_records", "plz4hip_mgpu_decode_records",
+    "plz4hip_mgpu_dev_encode_frame", "plz4hip_mgpu_dev_decode_frame",
 ]
 
 E_NAMES = {0: "OK", -1: "E_ARG", -2: "E_DEVICE", -3: "E_NOMEM", -4: "E_UNSUPPORTED"}
@@ -120,6 +123,30 @@ def load():
     L.plz4hip_ctx_set_content_hash.argtypes = [vp, vp]
     L.plz4hip_ctx_trim.restype = C.c_int
     L.plz4hip_ctx_trim.argtypes = [vp]
+    L.plz4hip_mgpu_create.restype = C.c_int
+    L.plz4hip_mgpu_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    L.plz4hip_mgpu_destroy.restype = None
+    L.plz4hip_mgpu_destroy.argtypes = [vp]
+    L.plz4hip_mgpu_count.restype = C.c_int
+    L.plz4hip_mgpu_count.argtypes = [vp]
+    L.plz4hip_mgpu_ctx.restype = C.c_void_p
+    L.plz4hip_mgpu_ctx.argtypes = [vp, C.c_int]
+    L.plz4hip_mgpu_last_error.restype = C.c_char_p
+    L.plz4hip_mgpu_last_error.argtypes = [vp]
+    L.plz4hip_mgpu_compress_batch.restype = C.c_int
+    L.plz4hip_mgpu_compress_batch.argtypes = [vp, C.c_int, pp, i32p, pp, i32p, C.c_int, i32p]
+    L.plz4hip_mgpu_decompress_batch.restype = C.c_int
+    L.plz4hip_mgpu_decompress_batch.argtypes = [vp, C.c_int, pp, i32p, pp, i32p, i32p]
+    L.plz4hip_mgpu_encode_records.restype = C.c_int
+    L.plz4hip_mgpu_encode_records.argtypes = [vp, C.c_int, pp, i32p, C.c_int, C.c_int, C.c_int, pp, i32p]
+    L.plz4hip_mgpu_decode_records.restype = C.c_int
+    L.plz4hip_mgpu_decode_records.argtypes = [vp, C.c_int, pp, i32p, C.c_int, C.c_int, pp, i32p, i32p]
+    L.plz4hip_mgpu_dev_encode_frame.restype = C.c_int
+    L.plz4hip_mgpu_dev_encode_frame.argtypes = [vp, C.c_int, pp, C.POINTER(C.c_int64), C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int64,
+                                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.plz4hip_mgpu_dev_decode_frame.restype = C.c_int
+    L.plz4hip_mgpu_dev_decode_frame.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int64), C.c_int, C.c_int, pp, C.c_int64, C.c_int,
+                                                i32p, i32p]
     if L.plz4hip_abi_version() != ABI_VERSION:
         raise ImportError("plz4_amd: libplz4hip.so ABI %d != binding %d" % (L.plz4hip_abi_version(), ABI_VERSION))
     _lib = L
@@ -334,3 +361,70 @@ class Engine:
 
     def trim(self):
         self._chk(self.L.plz4hip_ctx_trim(self.h))
+
+
+class MultiEngine:
+    """plz4hip_mgpu: block i of a call runs on device i mod G (section D of include/plz4hip.h)."""
+
+    def __init__(self, devices):
+        self.L = load()
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.L.plz4hip_mgpu_create(arr, len(devices), C.byref(h))
+        if rc != 0:
+            raise EngineError(rc, "plz4hip_mgpu_create")
+        self.h = h
+        self.g = len(devices)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.plz4hip_mgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise EngineError(rc, (self.L.plz4hip_mgpu_last_error(self.h) or b"").decode())
+
+    def encode_records(self, srcs, bsz, block_checksum, level=1):
+        n = len(srcs)
+        recs = [np.empty(bsz + 8, dtype=np.uint8) for _ in range(n)]
+        lens = _i32([s.size for s in srcs]); rl = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self.L.plz4hip_mgpu_encode_records(self.h, n, _ptr_array(srcs), _i32p(lens), bsz, level, int(block_checksum),
+                                                     _ptr_array(recs), _i32p(rl)))
+        return [r[:int(k)] for r, k in zip(recs, rl[:n])]
+
+    def decode_records(self, recs, bsz, block_checksum):
+        n = len(recs)
+        dsts = [np.empty(bsz + 8, dtype=np.uint8) for _ in range(n)]
+        lens = _i32([r.size for r in recs]); res = np.zeros(max(n, 1), dtype=np.int32); st = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self.L.plz4hip_mgpu_decode_records(self.h, n, _ptr_array(recs), _i32p(lens), bsz, int(block_checksum),
+                                                     _ptr_array(dsts), _i32p(res), _i32p(st)))
+        return res[:n], st[:n], [d[:max(int(r), 0)] for d, r in zip(dsts, res[:n])]
+
+    def compress_batch(self, srcs, caps, level=1):
+        n = len(srcs)
+        dsts = [np.empty(max(c, 1), dtype=np.uint8) for c in caps]
+        lens = _i32([s.size for s in srcs]); cp = _i32(caps); res = np.zeros(max(n, 1), dtype=np.int32)
+        self._chk(self.L.plz4hip_mgpu_compress_batch(self.h, n, _ptr_array(srcs), _i32p(lens), _ptr_array(dsts), _i32p(cp), level, _i32p(res)))
+        return res[:n], [d[:max(int(r), 0)] for d, r in zip(dsts, res[:n])]
+
+    def dev_encode_frame(self, shard_ptrs, shard_bytes, nblocks, bsz, block_checksum, owner, body_ptr, body_cap, level=1):
+        sp = (C.c_void_p * self.g)(*shard_ptrs); sb = (C.c_int64 * self.g)(*shard_bytes)
+        off = (C.c_int64 * (nblocks + 1))(); total = C.c_int64()
+        self._chk(self.L.plz4hip_mgpu_dev_encode_frame(self.h, nblocks, sp, sb, bsz, level, int(block_checksum), owner, body_ptr, body_cap,
+                                                       off, C.byref(total)))
+        return np.array(off[:], dtype=np.int64), int(total.value)
+
+    def dev_decode_frame(self, nblocks, owner, body_ptr, rec_off, bsz, block_checksum, shard_dst_ptrs, dst_stride, dst_cap):
+        off = (C.c_int64 * (nblocks + 1))(*[int(x) for x in rec_off])
+        dp = (C.c_void_p * self.g)(*shard_dst_ptrs)
+        res = np.zeros(max(nblocks, 1), dtype=np.int32); st = np.zeros(max(nblocks, 1), dtype=np.int32)
+        self._chk(self.L.plz4hip_mgpu_dev_decode_frame(self.h, nblocks, owner, body_ptr, off, bsz, int(block_checksum), dp, dst_stride, dst_cap,
+                                                       _i32p(res), _i32p(st)))
+        return res[:nblocks], st[:nblocks]
