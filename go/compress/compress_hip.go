@@ -34,14 +34,17 @@ type BatchDecompressor interface {
 
 type LevelT int
 
+// One engine per process over EVERY GPU of the node (plz4hip_mgpu, section D of plz4hip.h): block i of a batch runs on device
+// i mod G, each device behind its own ctx, so concurrent writers are serialised per device only -- not behind one global ctx.
+// PLZ4_HIP_DEVICES=0,2,5 restricts the set (default: all of them).
 var (
 	once sync.Once
-	ctx  *plz4hip.Ctx
+	ctx  *plz4hip.Multi
 	cerr error
 )
 
-func engine() (*plz4hip.Ctx, error) {
-	once.Do(func() { ctx, cerr = plz4hip.NewCtx(0) })
+func engine() (*plz4hip.Multi, error) {
+	once.Do(func() { ctx, cerr = plz4hip.NewMulti(plz4hip.DevicesFromEnv()) })
 	return ctx, cerr
 }
 
@@ -106,7 +109,7 @@ func (d *DictT) device(e *plz4hip.Ctx) (*plz4hip.Dict, error) {
 		return nil, nil
 	}
 	if d.dev == nil {
-		dd, err := e.NewDict(d.Data)
+		dd, err := e.Ctx(0).NewDict(d.Data)
 		if err != nil {
 			return nil, err
 		}
@@ -134,7 +137,7 @@ func (c *hipDictCompressor) EncodeRecords(src, rec [][]byte, bsz int, blockCheck
 	if err != nil {
 		return nil, err
 	}
-	n, err := e.EncodeRecordsEx(src, rec, bsz, int(c.level), blockChecksum, c.linked, dd, c.tail)
+	n, err := e.Ctx(0).EncodeRecordsEx(src, rec, bsz, int(c.level), blockChecksum, c.linked, dd, c.tail)
 	if err == nil && c.linked && c.level > 1 {
 		// linkedCompressorHC.Compress returns liblz4's "does not fit" without joining zerr.ErrCompress (compress/linked.go:47-49),
 		// so blk.CompressToBlk does not store the block raw there (blk/blk.go:75-86): the write fails.  Kept.
@@ -166,7 +169,7 @@ func (c *hipDictCompressor) Compress(src, dst, _ []byte) (int, error) {
 	if c.linked {
 		return 0, errors.New("plz4_hip: linked blocks go through EncodeRecords (the frame writer), not through Compress")
 	}
-	n, err := e.CompressBatchDict([][]byte{src}, [][]byte{dst}, int(c.level), dd)
+	n, err := e.Ctx(0).CompressBatchDict([][]byte{src}, [][]byte{dst}, int(c.level), dd)
 	if err != nil {
 		return 0, err
 	}
@@ -195,7 +198,7 @@ func (c *hipDictDecompressor) Decompress(src, dst []byte) (int, error) {
 	if c.linked {
 		return 0, errors.New("plz4_hip: linked blocks go through DecodeRecords (the frame reader), not through Decompress")
 	}
-	n, err := e.DecompressBatchDict([][]byte{src}, [][]byte{dst}, dd)
+	n, err := e.Ctx(0).DecompressBatchDict([][]byte{src}, [][]byte{dst}, dd)
 	if err != nil {
 		return 0, err
 	}
@@ -215,7 +218,7 @@ func (c *hipDictDecompressor) DecodeRecords(rec, dst [][]byte, bsz int, blockChe
 		return nil, nil, err
 	}
 	if !c.linked {
-		return e.DecodeRecordsEx(rec, dst, bsz, blockChecksum, false, dd, nil, nil)
+		return e.Ctx(0).DecodeRecordsEx(rec, dst, bsz, blockChecksum, false, dd, nil, nil)
 	}
 	if c.window == nil { // the window starts as the dictionary's last 64 KiB (compress/dict.go:43-56)
 		c.window = make([]byte, 65536)
@@ -223,7 +226,7 @@ func (c *hipDictDecompressor) DecodeRecords(rec, dst [][]byte, bsz int, blockChe
 			c.wlen = copy(c.window, c.dict.Data)
 		}
 	}
-	return e.DecodeRecordsEx(rec, dst, bsz, blockChecksum, true, nil, c.window, &c.wlen)
+	return e.Ctx(0).DecodeRecordsEx(rec, dst, bsz, blockChecksum, true, nil, c.window, &c.wlen)
 }
 
 type CompressorFactory struct {

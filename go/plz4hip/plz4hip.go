@@ -18,7 +18,10 @@ import "C"
 import (
 	"errors"
 	"fmt"
+	"os"
 	"runtime"
+	"strconv"
+	"strings"
 	"unsafe"
 )
 
@@ -329,4 +332,109 @@ func b2i(b bool) C.int {
 		return 1
 	}
 	return 0
+}
+
+
+// ---- several GPUs behind one handle (plz4hip_mgpu, section D of plz4hip.h): block i of a batch runs on device i mod G.
+// Multi offers the batch calls of Ctx; what needs a single device's state (dictionaries, linked decode chains, the content
+// checksum stream) goes through Ctx(k).
+type Multi struct {
+	p    *C.plz4hip_mgpu
+	ctxs []*Ctx
+}
+
+// DevicesFromEnv: PLZ4_HIP_DEVICES="0,2,5", or every device of the node.
+func DevicesFromEnv() []int {
+	var out []int
+	if v := os.Getenv("PLZ4_HIP_DEVICES"); v != "" {
+		for _, f := range strings.Split(v, ",") {
+			if d, err := strconv.Atoi(strings.TrimSpace(f)); err == nil {
+				out = append(out, d)
+			}
+		}
+	}
+	if len(out) == 0 {
+		n := int(C.plz4hip_device_count())
+		for d := 0; d < n; d++ {
+			out = append(out, d)
+		}
+	}
+	return out
+}
+
+func NewMulti(devices []int) (*Multi, error) {
+	if len(devices) == 0 {
+		return nil, fmt.Errorf("%w: no device", ErrEngine)
+	}
+	dv := make([]C.int, len(devices))
+	for i, d := range devices {
+		dv[i] = C.int(d)
+	}
+	m := &Multi{}
+	if rc := C.plz4hip_mgpu_create(&dv[0], C.int(len(dv)), &m.p); rc != C.PLZ4HIP_OK {
+		return nil, fmt.Errorf("%w: plz4hip_mgpu_create = %d", ErrEngine, int(rc))
+	}
+	for k := range devices {
+		m.ctxs = append(m.ctxs, &Ctx{p: C.plz4hip_mgpu_ctx(m.p, C.int(k))})
+	}
+	return m, nil
+}
+
+func (m *Multi) Close()         { C.plz4hip_mgpu_destroy(m.p); m.p = nil }
+func (m *Multi) Ctx(k int) *Ctx { return m.ctxs[k%len(m.ctxs)] }
+func (m *Multi) err(rc C.int) error {
+	return fmt.Errorf("%w: %d: %s", ErrEngine, int(rc), C.GoString(C.plz4hip_mgpu_last_error(m.p)))
+}
+
+func (m *Multi) CompressBatch(src, dst [][]byte, level int) ([]int, error) {
+	s, d := newBatch(src, false), newBatch(dst, false)
+	defer s.free()
+	defer d.free()
+	res := make([]C.int32_t, len(src))
+	if rc := C.plz4hip_mgpu_compress_batch(m.p, C.int(len(src)), (*unsafe.Pointer)(s.ptrs), i32p(s.lens), (*unsafe.Pointer)(d.ptrs), i32p(d.lens), C.int(level), i32p(res)); rc != C.PLZ4HIP_OK {
+		return nil, m.err(rc)
+	}
+	return toInts(res), nil
+}
+
+func (m *Multi) DecompressBatch(src, dst [][]byte) ([]int, error) {
+	s, d := newBatch(src, false), newBatch(dst, false)
+	defer s.free()
+	defer d.free()
+	res := make([]C.int32_t, len(src))
+	if rc := C.plz4hip_mgpu_decompress_batch(m.p, C.int(len(src)), (*unsafe.Pointer)(s.ptrs), i32p(s.lens), (*unsafe.Pointer)(d.ptrs), i32p(d.lens), i32p(res)); rc != C.PLZ4HIP_OK {
+		return nil, m.err(rc)
+	}
+	return toInts(res), nil
+}
+
+func (m *Multi) EncodeRecords(src, rec [][]byte, bsz, level int, blockChecksum bool) ([]int, error) {
+	s, r := newBatch(src, false), newBatch(rec, true)
+	defer s.free()
+	defer r.free()
+	res := make([]C.int32_t, len(src))
+	if rc := C.plz4hip_mgpu_encode_records(m.p, C.int(len(src)), (*unsafe.Pointer)(s.ptrs), i32p(s.lens), C.int(bsz), C.int(level), b2i(blockChecksum), (*unsafe.Pointer)(r.ptrs), i32p(res)); rc != C.PLZ4HIP_OK {
+		return nil, m.err(rc)
+	}
+	return toInts(res), nil
+}
+
+func (m *Multi) DecodeRecords(rec, dst [][]byte, bsz int, blockChecksum bool) ([]int, []int, error) {
+	r, d := newBatch(rec, false), newBatch(dst, true)
+	defer r.free()
+	defer d.free()
+	res := make([]C.int32_t, len(rec))
+	st := make([]C.int32_t, len(rec))
+	if rc := C.plz4hip_mgpu_decode_records(m.p, C.int(len(rec)), (*unsafe.Pointer)(r.ptrs), i32p(r.lens), C.int(bsz), b2i(blockChecksum), (*unsafe.Pointer)(d.ptrs), i32p(res), i32p(st)); rc != C.PLZ4HIP_OK {
+		return nil, nil, m.err(rc)
+	}
+	return toInts(res), toInts(st), nil
+}
+
+func toInts(v []C.int32_t) []int {
+	out := make([]int, len(v))
+	for i, x := range v {
+		out[i] = int(x)
+	}
+	return out
 }
