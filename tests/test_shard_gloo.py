@@ -22,7 +22,7 @@ def _torch_scatter(src, src_off, lens, dst_off, n, max_len, dst):
         dst[d:d + l] = src[a:a + l]
 
 
-def _worker(rank, world, port, nblk, bsz, q):
+def _worker(rank, world, port, nblk, bsz, q, piece=None):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,7 +34,8 @@ def _worker(rank, world, port, nblk, bsz, q):
     recs = [orc.block_record(data[g * bsz:(g + 1) * bsz], bsz, True) for g in mine]
     body = torch.from_numpy(np.concatenate(recs))
     rec_len = torch.tensor([r.size for r in recs], dtype=torch.int32)
-    frame, total = shard.gather_frame_body(body, rec_len, rank, world, _torch_scatter, {}, bsz + 8)
+    kw = {} if piece is None else {"piece": piece}
+    frame, total = shard.gather_frame_body(body, rec_len, rank, world, _torch_scatter, {}, bsz + 8, **kw)
     if rank == 0:
         want = orc.frame_encode(data, 4, True, False)[7:-4]
         q.put((total == want.size, bool(np.array_equal(frame[:total].numpy(), want))))
@@ -52,6 +53,26 @@ def test_round_robin_gather_world2():
     for p in procs: p.join(timeout=60)
     assert ok == (True, True)
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_round_robin_gather_in_pieces_world3():
+    """The bodies travel in pieces of whole records through two scratch pieces per sender (here ~2 records per piece, 5 rounds)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, 27, 64 << 10, q, 100000)) for r in range(3)]
+    for p in procs: p.start()
+    ok = q.get(timeout=180)
+    for p in procs: p.join(timeout=60)
+    assert ok == (True, True)
+    assert all(p.exitcode == 0 for p in procs)
+
+
+def test_piece_cuts():
+    from plz4_amd import shard
+    assert shard.piece_cuts([5, 5, 5, 5], 10) == [0, 2, 4]
+    assert shard.piece_cuts([50, 5, 5], 10) == [0, 1, 3]              # a record larger than a piece travels alone
+    assert shard.piece_cuts([], 10) == [0, 0]
 
 
 def test_interleave_offsets():
