@@ -4,15 +4,19 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 6144
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
+note = sys.argv[3] if len(sys.argv) > 3 else None
 out = os.path.join(root, "profiles"); os.makedirs(out, exist_ok=True)
 
+import re
 def short(k):
-    for n in ("k_encode_rec", "k_decode_rec", "k_move_records", "k_scan", "k_encode_raw", "k_decode_raw", "k_xxh32"):
-        if n in k: return n
-    return None
+    """The library's kernels by their base name (template arguments and the namespace dropped): k_encode_rec, k_decode_rec,
+    k_hc12_search, k_encode_rec_hc, k_encode_rec_dict, k_decode_rec_linked, ..."""
+    m = re.search(r"\b(k_[a-z0-9_]+)", k)
+    return m.group(1) if m else None
 
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 summary = {"tag": tag, "blocks_per_gpu": B, "kernels": {}}
+if note: summary["workload"] = note
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     keep = [r for r in rows if short(r["Name"])]
@@ -31,8 +35,9 @@ for d in ("fetch", "write", "sq1", "sq2"):
 for k, cs in pmc.items():
     e = summary["kernels"].setdefault(k, {})
     e["pmc_per_launch"] = {c: sum(v) / len(v) for c, v in cs.items()}
+    e["pmc_launches"] = {c: len(v) for c, v in cs.items()}
 S = B * (4 << 20)
-for k in ("k_encode_rec", "k_decode_rec"):
+for k in list(summary["kernels"]):
     p = summary["kernels"].get(k, {}).get("pmc_per_launch", {})
     if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
         # rocprofv3 reports KiB.  MI355X_MICROARCH.md §HBM: FETCH_SIZE reads 1/2 of the bytes of wide coalesced streams on
