@@ -502,25 +502,26 @@ struct Hc12Walk {
 // The price table (LZ4HC_optimal_t opt[LZ4_OPT_NUM + TRAILING_LITERALS], :1770-1775, :1836) as three arrays; entries below
 // `nl` live in LDS, the rest (windows that long are rare) in a per-wave global workspace.  mloff = mlen << 16 | off
 // (mlen <= 4095 inside the table, :1948-1956).
+struct __attribute__((aligned(16))) Hc12Ent { int price; int litlen; uint32_t mloff; uint32_t pad; };   // one 16-byte LDS access per entry
 struct Hc12Ws {
-    int* price; int* litlen; uint32_t* mloff; int nl;          // LDS
+    Hc12Ent* ent; int nl;                                      // LDS
     int* gprice; int* glitlen; uint32_t* gmloff;               // global, index - nl
     uint64_t* seq;                                             // LDS: 64 pending sequences, pos | ml << 23 | off << 46
 };
 enum : int { kHc12WsGlobalBytes = kHc12OptEntries * 12 };
 
-#define HC12_PRICE(i)  ((i) < w.nl ? w.price[(i)]  : w.gprice[(i) - w.nl])
-#define HC12_LITLEN(i) ((i) < w.nl ? w.litlen[(i)] : w.glitlen[(i) - w.nl])
-#define HC12_MLOFF(i)  ((i) < w.nl ? w.mloff[(i)]  : w.gmloff[(i) - w.nl])
+#define HC12_PRICE(i)  ((i) < w.nl ? w.ent[(i)].price  : w.gprice[(i) - w.nl])
+#define HC12_LITLEN(i) ((i) < w.nl ? w.ent[(i)].litlen : w.glitlen[(i) - w.nl])
+#define HC12_MLOFF(i)  ((i) < w.nl ? w.ent[(i)].mloff  : w.gmloff[(i) - w.nl])
 // K (a compile-time flag): every index of this step lies below w.nl, i.e. in LDS
-#define HC12K_PRICE(i)  (K ? w.price[(i)]  : HC12_PRICE(i))
-#define HC12K_LITLEN(i) (K ? w.litlen[(i)] : HC12_LITLEN(i))
-#define HC12K_MLOFF(i)  (K ? w.mloff[(i)]  : HC12_MLOFF(i))
-#define HC12K_SET(i, pr, ll, mo) do { if (K) { const int k_ = (i); w.price[k_] = (pr); w.litlen[k_] = (ll); w.mloff[k_] = (mo); } else HC12_SET(i, pr, ll, mo); } while (0)
+#define HC12K_PRICE(i)  (K ? w.ent[(i)].price  : HC12_PRICE(i))
+#define HC12K_LITLEN(i) (K ? w.ent[(i)].litlen : HC12_LITLEN(i))
+#define HC12K_MLOFF(i)  (K ? w.ent[(i)].mloff  : HC12_MLOFF(i))
+#define HC12K_SET(i, pr, ll, mo) do { if (K) { Hc12Ent e_; e_.price = (pr); e_.litlen = (ll); e_.mloff = (mo); e_.pad = 0; w.ent[(i)] = e_; } else HC12_SET(i, pr, ll, mo); } while (0)
 struct Hc12InLds { static constexpr bool value = true; };
 struct Hc12Anywhere { static constexpr bool value = false; };
 #define HC12_SET(i, pr, ll, mo) do { const int i_ = (i); \
-        if (i_ < w.nl) { w.price[i_] = (pr); w.litlen[i_] = (ll); w.mloff[i_] = (mo); } \
+        if (i_ < w.nl) { Hc12Ent e_; e_.price = (pr); e_.litlen = (ll); e_.mloff = (mo); e_.pad = 0; w.ent[i_] = e_; } \
         else { w.gprice[i_ - w.nl] = (pr); w.glitlen[i_ - w.nl] = (ll); w.gmloff[i_ - w.nl] = (mo); } } while (0)
 
 // == LZ4HC_compress_optimal(nbSearches 16384, sufficient_len 4095, fullUpdate) + the last literals (:1823-2123) over the
@@ -532,6 +533,8 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
     const bool limited = cap < compress_bound(n);                                          // :1505-1508
     const int mflimit = n - kMfLimit;
     int ip = 0, anchor = 0, op = 0, nseq = 0;
+    STAT_DECL;                              // diagnostics build only: cycles per part of the parser (scripts/stats_probe12.py)
+    const unsigned long long tP0 = STAT_NOW(); (void)tP0;
 
     // F of 64 consecutive positions, one per lane (the next window is requested ahead)
     LV(int, fLen); LV(int, fOff); LV(int, gLen); LV(int, gOff);
@@ -556,7 +559,8 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
     // ---- the writer: LZ4HC_encodeSequence (:268-354) for up to 64 recorded sequences at once, one per lane
     auto flush = [&]() -> bool {
         if (!nseq) return true;
-        LDS_FENCE();
+        const unsigned long long tf0 = STAT_NOW(); (void)tf0;
+        LDS_ORDER();
         const int cnt = nseq, anchor0 = anchor, op0 = op;
         nseq = 0;
         LV(int, sp); LV(int, sm); LV(int, so); LV(int, an); LV(int, lit); LV(int, xl); LV(int, xm); LV(int, acc); LV(int, sz);
@@ -617,6 +621,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         }
         anchor = RL(sp, cnt - 1) + RL(sm, cnt - 1);
         op = opEnd;
+        STAT(5, STAT_NOW() - tf0); STAT(9, cnt);
         return true;
     };
     auto push_seq = [&](int pos, int ml, int off) -> bool {
@@ -631,6 +636,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
 
     while (ip <= mflimit) {                                                                // :1863
         // ---- the next position with a match: F.len != 0 (positions without one only move ip, :1868)
+        const unsigned long long tA = STAT_NOW(); (void)tA;
         f_window(ip);
         uint64_t any;
         {
@@ -643,6 +649,8 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         if (first.len == kHc12NotComputed) first = search_now(ip);
         if (first.len == 0) { ip++; continue; }
         const int llen = ip - pendEnd;
+        STAT(0, STAT_NOW() - tA);
+        const unsigned long long tB = STAT_NOW(); (void)tB;
         if (first.len > kHc12Sufficient) {                                                 // :1871-1882
             if (!push_seq(ip, first.len, first.off)) return 0;
             ip += first.len; pendEnd = ip;
@@ -661,12 +669,14 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                 })
             }
         }
-        LDS_FENCE();
+        LDS_ORDER();
+        STAT(1, STAT_NOW() - tB); STAT(7, 1);
         int last = first.len, cur = 1;
         int bestMl = 0, bestOff = 0; bool direct = false;
         // ---- the DP (:1922-2019)
         for (;;) {
             if (cur >= last || ip + cur > mflimit) break;
+            const unsigned long long tC = STAT_NOW(); (void)tC;
             f_window(ip + cur);
             LV(int, p0); LV(int, ll0); LV(uint32_t, mo0);
             uint64_t need;
@@ -678,7 +688,8 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                     p0[I_] = 0; ll0[I_] = 0; mo0[I_] = 0;
                     int want = 0;
                     if (c >= curL && c < lastL && pos <= mflimit && fLen[I_] != 0) {
-                        p0[I_] = HC12K_PRICE(c); ll0[I_] = HC12K_LITLEN(c); mo0[I_] = HC12K_MLOFF(c);
+                        if (K) { const Hc12Ent e = w.ent[c]; p0[I_] = e.price; ll0[I_] = e.litlen; mo0[I_] = e.mloff; }
+                        else { p0[I_] = HC12_PRICE(c); ll0[I_] = HC12_LITLEN(c); mo0[I_] = HC12_MLOFF(c); }
                         const int p1 = HC12K_PRICE(c + 1), p4 = HC12K_PRICE(c + kMinMatch);
                         want = !(p1 <= p0[I_] && p4 < p0[I_] + 3);                          // fullUpdate skip test, :1929-1931
                     }
@@ -687,6 +698,8 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                 need = BALLOT(ll0[I_] < 0);
             };
             if (last + 8 < w.nl) scan(Hc12InLds{}); else scan(Hc12Anywhere{});
+            STAT(2, STAT_NOW() - tC); STAT(10, 1);
+            const unsigned long long tD = STAT_NOW(); (void)tD;
             if (!need) { cur = fBase + 64 - ip; continue; }
             const int s = ctz64(need);
             const int c = fBase + s - ip;
@@ -700,43 +713,78 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
             const int mlenC = (int)(RL(mo0, s) >> 16);
             const int ll = (mlenC == 1) ? baseLit : 0;                                     // :1976-1982
             const int lastOld = last;
+            STAT(12, STAT_NOW() - tD);
             auto update = [&](auto tag) {
                 constexpr bool K = decltype(tag)::value;
-                bool tookLast = false;
-                const int basePrice = (mlenC == 1) ? ((c > ll) ? UNI(HC12K_PRICE(c - ll)) : 0) : priceC;
                 const int nmLen = nm.len; const uint32_t nmOff = (uint32_t)nm.off;
                 const int litBase = priceC - hc_lit_price(baseLit);
-                for (int t0 = 1; t0 <= nmLen; t0 += 64) {
-                    LV(int, took);
+                const bool needBase = (mlenC == 1) && (c > ll);
+                // ONE round of LDS reads for the whole step: the prices the first 64 lengths compare with (one per lane), the
+                // base price and the price at `last` (same address in every lane); everything after it is arithmetic and stores
+                LV(int, old); LV(int, bpl); LV(int, newp); LV(int, took);
+                {
+                    const int bpAt = needBase ? c - ll : c;
+                    LANES({
+                        const int t = 1 + LANE, pos = c + t;
+                        old[I_] = (t <= nmLen && pos <= lastOld + kHcTrailing) ? HC12K_PRICE(pos) : 0x7FFFFFFF;
+                        bpl[I_] = LANE == 0 ? HC12K_PRICE(bpAt) : (LANE == 1 ? HC12K_PRICE(lastOld) : 0);
+                    })
+                }
+                const int basePrice = (mlenC == 1) ? (needBase ? RL(bpl, 0) : 0) : priceC;
+                const int plOld = RL(bpl, 1);
+                STAT(13, STAT_NOW() - tD);
+                // the part of price(ll, ml) that does not depend on the lane (below 274 the length code is one extra byte from 19 on:
+                // no division per lane)
+                const int seq0 = basePrice + 1 + 2 + hc_lit_price(ll);
+                LANES({
+                    const int t = 1 + LANE, pos = c + t;
+                    took[I_] = 0; newp[I_] = old[I_];
+                    if (t <= nmLen) {
+                        if (t < kMinMatch) {                                               // literals after cur, :1958-1972
+                            const int pr = litBase + hc_lit_price(baseLit + t);
+                            if (pr < old[I_]) { newp[I_] = pr; HC12K_SET(pos, pr, baseLit + t, 1u << 16); }
+                        } else {                                                           // every length of the match, :1984-2008
+                            const int pr = seq0 + (t >= 19 ? 1 : 0);                       // == basePrice + hc_seq_price(ll, t), t <= 64
+                            if (pr <= old[I_]) {                                           // (an entry past last + 3 reads as +inf: always taken)
+                                took[I_] = 1; newp[I_] = pr;
+                                HC12K_SET(pos, pr, ll, ((uint32_t)t << 16) | nmOff);
+                            }
+                        }
+                    }
+                })
+                bool tookLast = nmLen <= 64 ? RL(took, (nmLen - 1) & 63) != 0 : false;
+                STAT(14, STAT_NOW() - tD);
+                for (int t0 = 65; t0 <= nmLen; t0 += 64) {                                 // lengths past 64: rare
                     LANES({
                         const int t = t0 + LANE;
                         took[I_] = 0;
                         if (t <= nmLen) {
                             const int pos = c + t;
-                            if (t < kMinMatch) {                                           // literals after cur, :1958-1972
-                                const int pr = litBase + hc_lit_price(baseLit + t);
-                                if (pr < HC12K_PRICE(pos)) HC12K_SET(pos, pr, baseLit + t, 1u << 16);
-                            } else {                                                       // every length of the match, :1984-2008
-                                const int pr = basePrice + hc_seq_price(ll, t);
-                                if (pos > lastOld + kHcTrailing || pr <= HC12K_PRICE(pos)) {
-                                    took[I_] = 1;
-                                    HC12K_SET(pos, pr, ll, ((uint32_t)t << 16) | nmOff);
-                                }
+                            const int pr = basePrice + hc_seq_price(ll, t);
+                            if (pos > lastOld + kHcTrailing || pr <= HC12K_PRICE(pos)) {
+                                took[I_] = 1;
+                                HC12K_SET(pos, pr, ll, ((uint32_t)t << 16) | nmOff);
                             }
                         }
                     })
                     if (nmLen - t0 < 64) tookLast = RL(took, nmLen - t0) != 0;
                 }
-                if (tookLast && lastOld < c + nmLen) last = c + nmLen;
-                LDS_FENCE();
-                {   const int pl = UNI(HC12K_PRICE(last)); const int lastL = last;          // :2011-2018
+                int pl;                                                                    // the price at `last` after this step
+                if (tookLast && lastOld < c + nmLen) { last = c + nmLen; pl = basePrice + hc_seq_price(ll, nmLen); }
+                else if (lastOld > c && lastOld - c <= 64 && lastOld - c <= nmLen) pl = RL(newp, lastOld - c - 1);
+                else if (lastOld > c && lastOld - c <= nmLen) { LDS_ORDER(); pl = UNI(HC12K_PRICE(lastOld)); }
+                else pl = plOld;
+                LDS_ORDER();
+                {   const int lastL = last;                                                // :2011-2018
                     LANES({ if (LANE >= 1 && LANE <= kHcTrailing) HC12K_SET(lastL + LANE, pl + hc_lit_price(LANE), LANE, 1u << 16); })
                 }
-                LDS_FENCE();
+                LDS_ORDER();
             };
             if ((lastOld > c + nm.len ? lastOld : c + nm.len) + 8 < w.nl) update(Hc12InLds{}); else update(Hc12Anywhere{});
+            STAT(3, STAT_NOW() - tD); STAT(6, 1);
             cur = c + 1;
         }
+        const unsigned long long tE = STAT_NOW(); (void)tE;
         if (!direct) {                                                                     // :2022-2024
             const uint32_t mo = UNI(HC12_MLOFF(last));
             bestMl = (int)(mo >> 16); bestOff = (int)(mo & 0xFFFFu);
@@ -747,8 +795,8 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
             int cand = cur; uint32_t sel = ((uint32_t)bestMl << 16) | (uint32_t)(bestOff & 0xFFFF);
             for (;;) {
                 const uint32_t nx = UNI(HC12_MLOFF(cand));
-                { const int candL = cand; const uint32_t selL = sel; LANES({ if (LANE == 0) { if (candL < w.nl) w.mloff[candL] = selL; else w.gmloff[candL - w.nl] = selL; } }) }
-                LDS_FENCE();
+                { const int candL = cand; const uint32_t selL = sel; LANES({ if (LANE == 0) { if (candL < w.nl) w.ent[candL].mloff = selL; else w.gmloff[candL - w.nl] = selL; } }) }
+                LDS_ORDER();
                 sel = nx;
                 const int nml = (int)(nx >> 16);
                 if (nml > cand) break;
@@ -767,6 +815,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                 ip += ml; pendEnd = ip;
             }
         }
+        STAT(4, STAT_NOW() - tE);
     }
     if (!flush()) return 0;
     // last literals (:2067-2098, limitedOutput / notLimited)
@@ -779,6 +828,8 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         wave_copy(dst + op, src + anchor, lastRun);
         op += lastRun;
     }
+    STAT(8, STAT_NOW() - tP0); STAT(11, 1);
+    STAT_FLUSH();
     return op;
 }
 

@@ -559,12 +559,10 @@ __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
 constexpr int kH12OptLds = 1024;
 __global__ __launch_bounds__(64) void k_hc12_parse(CodecArgs a)
 {
-    __shared__ int      oPrice[kH12OptLds];
-    __shared__ int      oLitlen[kH12OptLds];
-    __shared__ uint32_t oMloff[kH12OptLds];
+    __shared__ Hc12Ent  oEnt[kH12OptLds];
     __shared__ uint64_t seqs[64];
     Hc12Ws w;
-    w.price = oPrice; w.litlen = oLitlen; w.mloff = oMloff; w.nl = kH12OptLds; w.seq = seqs;
+    w.ent = oEnt; w.nl = kH12OptLds; w.seq = seqs;
     {
         uint8_t* gws = a.h12Ws + (size_t)blockIdx.x * kHc12WsGlobalBytes;
         w.gprice = (int*)gws; w.glitlen = (int*)(gws + kHc12OptEntries * 4); w.gmloff = (uint32_t*)(gws + kHc12OptEntries * 8);

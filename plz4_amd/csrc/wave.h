@@ -39,6 +39,7 @@
 #define SCAN_MAX_EXCL(x) do { int m_ = 0; for (int s_ = 0; s_ < 64; ++s_) { const int v_ = (x)[s_]; (x)[s_] = m_; if (v_ > m_) m_ = v_; } } while (0)
 #define WAVE_FENCE()   do {} while (0)
 #define LDS_FENCE()    do {} while (0)
+#define LDS_ORDER()    do {} while (0)
 // Same-address LDS store conflicts inside one instruction are resolved in an unspecified lane order on
 // hardware; the emulation can run lanes ascending or descending so tests cover both resolutions.
 extern int plz4_emu_descending;
@@ -68,6 +69,9 @@ static inline int plz4_emu_step()  { return plz4_emu_descending ? -1 : 1; }
 // queue); the fence only stops the compiler from reordering the accesses.
 #define WAVE_FENCE()   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 #define LDS_FENCE()    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
+// Ordering of one wave's own LDS accesses only: the LDS executes a wave's instructions in issue order, so all that is needed is
+// that the compiler keeps them in program order (no counter wait: a fence also waits for every global store in flight).
+#define LDS_ORDER()    __asm__ volatile("" ::: "memory")
 
 __device__ __forceinline__ uint32_t plz4_readlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ int      plz4_readlane(int v, int l)      { return __builtin_amdgcn_readlane(v, l); }

@@ -196,11 +196,11 @@ extern "C" int emu_compress_hc12(const uint8_t* src, int n, uint8_t* dst, int ca
     }
     Hc12Ws w;
     w.nl = nl;
-    w.price = (int*)malloc(4 * (size_t)nl); w.litlen = (int*)malloc(4 * (size_t)nl); w.mloff = (uint32_t*)malloc(4 * (size_t)nl);
+    w.ent = (Hc12Ent*)aligned_alloc(16, sizeof(Hc12Ent) * (size_t)((nl + 3) & ~3));
     w.gprice = (int*)malloc(4 * kHc12OptEntries); w.glitlen = (int*)malloc(4 * kHc12OptEntries); w.gmloff = (uint32_t*)malloc(4 * kHc12OptEntries);
     uint64_t seq[64]; w.seq = seq;
     const int r = hc12_parse(E.padded, n, dst, cap, F, E.chain, w);
-    free(w.price); free(w.litlen); free(w.mloff); free(w.gprice); free(w.glitlen); free(w.gmloff);
+    free(w.ent); free(w.gprice); free(w.glitlen); free(w.gmloff);
     free(F);
     return r;
 }
