@@ -28,6 +28,19 @@
 #include "lz4_device.inl"
 #include "lz4hc_device.inl"
 
+// diagnostics build: the parser's and the search kernel's timers share one counter array, one of the two is compiled in
+#if defined(PLZ4_STATS_SEARCH)
+#define PSTAT(i, v)    do {} while (0)
+#define PSTAT_FLUSH()  do {} while (0)
+#define SSTAT(i, v)    STAT(i, v)
+#define SSTAT_FLUSH()  STAT_FLUSH()
+#else
+#define PSTAT(i, v)    STAT(i, v)
+#define PSTAT_FLUSH()  STAT_FLUSH()
+#define SSTAT(i, v)    do {} while (0)
+#define SSTAT_FLUSH()  do {} while (0)
+#endif
+
 namespace plz4 {
 
 enum : int { kHc12Sufficient = 4095,           // level 12: sufficient_len 4096, capped to LZ4_OPT_NUM - 1 (lz4hc.c:92-106, :1860)
@@ -621,7 +634,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         }
         anchor = RL(sp, cnt - 1) + RL(sm, cnt - 1);
         op = opEnd;
-        STAT(5, STAT_NOW() - tf0); STAT(9, cnt);
+        PSTAT(5, STAT_NOW() - tf0); PSTAT(9, cnt);
         return true;
     };
     auto push_seq = [&](int pos, int ml, int off) -> bool {
@@ -649,7 +662,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         if (first.len == kHc12NotComputed) first = search_now(ip);
         if (first.len == 0) { ip++; continue; }
         const int llen = ip - pendEnd;
-        STAT(0, STAT_NOW() - tA);
+        PSTAT(0, STAT_NOW() - tA);
         const unsigned long long tB = STAT_NOW(); (void)tB;
         if (first.len > kHc12Sufficient) {                                                 // :1871-1882
             if (!push_seq(ip, first.len, first.off)) return 0;
@@ -670,7 +683,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
             }
         }
         LDS_ORDER();
-        STAT(1, STAT_NOW() - tB); STAT(7, 1);
+        PSTAT(1, STAT_NOW() - tB); PSTAT(7, 1);
         int last = first.len, cur = 1;
         int bestMl = 0, bestOff = 0; bool direct = false;
         // ---- the DP (:1922-2019)
@@ -698,7 +711,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                 need = BALLOT(ll0[I_] < 0);
             };
             if (last + 8 < w.nl) scan(Hc12InLds{}); else scan(Hc12Anywhere{});
-            STAT(2, STAT_NOW() - tC); STAT(10, 1);
+            PSTAT(2, STAT_NOW() - tC); PSTAT(10, 1);
             const unsigned long long tD = STAT_NOW(); (void)tD;
             if (!need) { cur = fBase + 64 - ip; continue; }
             const int s = ctz64(need);
@@ -713,7 +726,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
             const int mlenC = (int)(RL(mo0, s) >> 16);
             const int ll = (mlenC == 1) ? baseLit : 0;                                     // :1976-1982
             const int lastOld = last;
-            STAT(12, STAT_NOW() - tD);
+            PSTAT(12, STAT_NOW() - tD);
             auto update = [&](auto tag) {
                 constexpr bool K = decltype(tag)::value;
                 const int nmLen = nm.len; const uint32_t nmOff = (uint32_t)nm.off;
@@ -732,7 +745,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                 }
                 const int basePrice = (mlenC == 1) ? (needBase ? RL(bpl, 0) : 0) : priceC;
                 const int plOld = RL(bpl, 1);
-                STAT(13, STAT_NOW() - tD);
+                PSTAT(13, STAT_NOW() - tD);
                 // the part of price(ll, ml) that does not depend on the lane (below 274 the length code is one extra byte from 19 on:
                 // no division per lane)
                 const int seq0 = basePrice + 1 + 2 + hc_lit_price(ll);
@@ -753,7 +766,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                     }
                 })
                 bool tookLast = nmLen <= 64 ? RL(took, (nmLen - 1) & 63) != 0 : false;
-                STAT(14, STAT_NOW() - tD);
+                PSTAT(14, STAT_NOW() - tD);
                 for (int t0 = 65; t0 <= nmLen; t0 += 64) {                                 // lengths past 64: rare
                     LANES({
                         const int t = t0 + LANE;
@@ -781,7 +794,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                 LDS_ORDER();
             };
             if ((lastOld > c + nm.len ? lastOld : c + nm.len) + 8 < w.nl) update(Hc12InLds{}); else update(Hc12Anywhere{});
-            STAT(3, STAT_NOW() - tD); STAT(6, 1);
+            PSTAT(3, STAT_NOW() - tD); PSTAT(6, 1);
             cur = c + 1;
         }
         const unsigned long long tE = STAT_NOW(); (void)tE;
@@ -815,7 +828,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
                 ip += ml; pendEnd = ip;
             }
         }
-        STAT(4, STAT_NOW() - tE);
+        PSTAT(4, STAT_NOW() - tE);
     }
     if (!flush()) return 0;
     // last literals (:2067-2098, limitedOutput / notLimited)
@@ -828,8 +841,8 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         wave_copy(dst + op, src + anchor, lastRun);
         op += lastRun;
     }
-    STAT(8, STAT_NOW() - tP0); STAT(11, 1);
-    STAT_FLUSH();
+    PSTAT(8, STAT_NOW() - tP0); PSTAT(11, 1);
+    PSTAT_FLUSH();
     return op;
 }
 

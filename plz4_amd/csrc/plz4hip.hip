@@ -453,6 +453,8 @@ __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
         __syncthreads();
 
         Hc12SrcRing sw; sw.ring = ring; sw.g = t.src; sw.hi = 0;
+        STAT_DECL;                              // diagnostics build: cycles and lane counts per section (scripts/stats_probe12.py)
+        const unsigned long long tS0 = STAT_NOW(); (void)tS0;
         Hc12Walk<Hc12SrcRing> L;
         L.phase = kPhIdle;                      // kPhIdle: wants a position; kPhWait: holds p, its bytes are not in the ring yet
         int p = 0;
@@ -470,7 +472,8 @@ __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
             const uint64_t mP = __builtin_amdgcn_ballot_w64(L.phase == kPhPattern);
             const uint64_t mI = __builtin_amdgcn_ballot_w64(L.phase == kPhIdle || L.phase == kPhWait);
             const bool busy = (mF | mC | mS | mK | mP) != 0;
-            if (mI && (__builtin_popcountll(mI) >= a.h12Idle || !busy)) {
+            const unsigned long long tq0 = STAT_NOW(); (void)tq0;
+            if (mI && (__builtin_popcountll(mI) >= a.h12Idle || !busy)) { SSTAT(13, 1);
                 // (1) this wave's lower bound on the positions it holds or may still take: published BEFORE it takes new ones
                 const int q0 = H12_LD(ctl.qNext);
                 int m = h12_wave_min((L.phase != kPhIdle && L.phase != kPhDone) ? p : 0x7FFFFFFF);
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
                 }
             }
             if (!__builtin_amdgcn_ballot_w64(L.phase != kPhDone)) break;
+            SSTAT(12, STAT_NOW() - tq0);
             sw.hi = (uint32_t)min(H12_LD(ctl.loaded), n);
             // One phase's code per section.  A section costs the same whether 3 or 60 lanes are in it, so it runs when enough
             // lanes have gathered; when no phase has that many, the fullest one runs (nothing ever waits for good).
@@ -536,21 +540,27 @@ __global__ __launch_bounds__(1024) void k_hc12_search(CodecArgs a)
                           cK = __builtin_popcountll(mK), cP = __builtin_popcountll(mP);
                 int top = cF; top = cC > top ? cC : top; top = cS > top ? cS : top; top = cK > top ? cK : top; top = cP > top ? cP : top;
                 const int need = top < a.h12Gather ? top : a.h12Gather;
+                unsigned long long tx = STAT_NOW(); (void)tx;
                 if (cF && cF >= need) {
+                    SSTAT(0, 1); SSTAT(1, cF);
                     const bool fl = L.phase == kPhFilter;
                     if (__builtin_amdgcn_ballot_w64(fl && !L.is_near())) { if (fl && !L.is_near() && L.filter_trip<false>(t, sw)) finish(); }
                     if (fl && L.is_near() && L.filter_trip<true>(t, sw)) finish();
+                    SSTAT(2, STAT_NOW() - tx); tx = STAT_NOW();
                 }
-                if (cC && cC >= need) { if (L.phase == kPhCount) L.count_trip(t, sw); }
-                if (cS && cS >= need) { if (L.phase == kPhScan && L.scan_trip(t)) finish(); }
-                if (cK && cK >= need) { if (L.phase == kPhRank) L.rank_trip(t); }
+                if (cC && cC >= need) { SSTAT(3, 1); SSTAT(4, cC); if (L.phase == kPhCount) L.count_trip(t, sw); SSTAT(5, STAT_NOW() - tx); tx = STAT_NOW(); }
+                if (cS && cS >= need) { SSTAT(6, 1); SSTAT(7, cS); if (L.phase == kPhScan && L.scan_trip(t)) finish(); SSTAT(8, STAT_NOW() - tx); tx = STAT_NOW(); }
+                if (cK && cK >= need) { SSTAT(9, 1); SSTAT(10, cK); if (L.phase == kPhRank) L.rank_trip(t); SSTAT(11, STAT_NOW() - tx); tx = STAT_NOW(); }
                 if (cP && cP >= need) { if (L.phase == kPhPattern && L.pattern_trip(t, sw)) finish(); }
             }
             if (!busy) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++idleTrips > (1u << 27)) { if (lane == 0) atomicExch(a.h12Err, 1); break; }      // never seen; bounds every spin
             } else idleTrips = 0;
+            SSTAT(14, 1);
         }
+        SSTAT(15, STAT_NOW() - tS0); SSTAT(16, 1);
+        SSTAT_FLUSH();
         __syncthreads();
     }
 }
