@@ -936,14 +936,15 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
     return PLZ4HIP_OK;
 }
 
-bool use_h12(const CodecArgs& a) { return a.level >= 12 && !a.hcEx && getenv("PLZ4HIP_HC12_OFF") == nullptr; }
+// (blocks of 8 MiB and more -- raw block API only -- keep the one-thread-per-block kernel: the writer packs positions into 23 bits)
+bool use_h12(const CodecArgs& a, int maxLen) { return a.level >= 12 && !a.hcEx && maxLen < (1 << 23) && getenv("PLZ4HIP_HC12_OFF") == nullptr; }
 
 // Enqueue one HC call of nb blocks (a: everything but queue / workspace filled in) on s.  rawMode: LZ4 blocks, else records.
 int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode)
 {
     if (int rc = hc_enter(c, s)) return rc;
     hipError_t e;
-    if (use_h12(a)) {
+    if (use_h12(a, maxLen)) {
         H12Plan pl;
         if (int rc = plan_h12(c, nb, maxLen, &pl)) return rc;
         a.h12Chain = (uint16_t*)c->d_h12; a.h12ChainStride = pl.chainStride;

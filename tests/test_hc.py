@@ -221,3 +221,22 @@ def test_gpu_hc12_groups_and_streams(ref, orc, monkeypatch):
             else:
                 assert rec[3] & 0x80 and np.array_equal(rec[4:-4], s), (lvl, i)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_hc12_block_sizes_beyond_the_frame_path(ref, orc):
+    """The raw block API takes blocks of any size: 5 MiB runs the three-phase kernels (positions beyond 22 bits), 9 MiB falls back
+    to the one-thread-per-block kernel (the three-phase writer packs positions into 23 bits); a batch of ragged sizes too."""
+    from plz4_amd._native import Engine
+    eng = Engine(0)
+    srcs = [synth.text((5 << 20) + 321, seed=5), synth.text(70001, seed=6), synth.text(13, seed=7), np.zeros(0, np.uint8), synth.text(12, seed=8)]
+    caps = [orc.bound(s.size) for s in srcs]
+    res, outs = eng.compress_batch(srcs, caps, level=12)
+    for s, cap, r, o in zip(srcs, caps, res, outs):
+        n, want = ref.compress_hc(s, cap, 12)
+        assert int(r) == n and np.array_equal(o, want[:n]), s.size
+    big = synth.text((9 << 20) + 5, seed=9)
+    res, outs = eng.compress_batch([big], [orc.bound(big.size)], level=12)
+    n, want = ref.compress_hc(big, orc.bound(big.size), 12)
+    assert int(res[0]) == n and np.array_equal(outs[0], want[:n])
+    eng.close()
