@@ -803,29 +803,78 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
             bestMl = (int)(mo >> 16); bestOff = (int)(mo & 0xFFFFu);
             cur = last - bestMl;
         }
-        {   // reverse traversal: mark the chosen path (:2026-2046)
-            // (a direct long match may not fit the 16 bits of length: it is the path's last sequence, bestMl is kept aside)
-            int cand = cur; uint32_t sel = ((uint32_t)bestMl << 16) | (uint32_t)(bestOff & 0xFFFF);
-            for (;;) {
-                const uint32_t nx = UNI(HC12_MLOFF(cand));
-                { const int candL = cand; const uint32_t selL = sel; LANES({ if (LANE == 0) { if (candL < w.nl) w.ent[candL].mloff = selL; else w.gmloff[candL - w.nl] = selL; } }) }
-                LDS_ORDER();
-                sel = nx;
-                const int nml = (int)(nx >> 16);
+        if (last <= 63 && last + 8 < w.nl) {
+            // A window that fits the wave (about half of them): the table's (mlen, offset) column in one LDS read, one entry per
+            // lane.  The reverse traversal (:2026-2046) is a walk over lanes (readlane per hop); it hands every node of the path
+            // the old entry of the node above it -- here: each path lane takes the entry of the next path lane above it -- and
+            // the forward pass (:2048-2064) visits exactly the path's nodes, so the sequences are the path lanes whose new
+            // length is not 1, at position ip + lane, in lane order.
+            LV(uint32_t, mo);
+            { const int top = cur; LANES({ mo[I_] = (LANE <= top) ? w.ent[LANE].mloff : 0u; }) }
+            uint64_t path = 0;
+            for (int cand = cur;;) {
+                path |= 1ull << cand;
+                const int nml = (int)(RL(mo, cand) >> 16);
                 if (nml > cand) break;
                 cand -= nml;
             }
-        }
-        {   // record the sequences in order (:2048-2064)
-            int r = 0;
-            while (r < last) {
-                const uint32_t mo = UNI(HC12_MLOFF(r));
-                int ml = (int)(mo >> 16); const int off = (int)(mo & 0xFFFFu);
-                if (direct && r == cur) ml = bestMl;                                    // may not fit the table's 16 bits
-                if (ml == 1) { ip++; r++; continue; }
-                r += ml;
-                if (!push_seq(ip, ml, off)) return 0;
-                ip += ml; pendEnd = ip;
+            LV(uint32_t, nv); LV(int, isSeq);
+            {
+                const uint64_t pathL = path; const int curL = cur; const bool directL = direct;
+                const uint32_t best = ((uint32_t)bestMl << 16) | (uint32_t)(bestOff & 0xFFFF);
+                LANES({
+                    const uint64_t above = (LANE < 63) ? (pathL >> (LANE + 1)) : 0;
+                    const int from = above ? LANE + 1 + ctz64(above) : LANE;
+                    nv[I_] = SHFL(mo, from);
+                    if (LANE == curL) nv[I_] = best;
+                    const int ml = (directL && LANE == curL) ? 2 : (int)(nv[I_] >> 16);      // (a direct match is a match whatever its 16 bits say)
+                    isSeq[I_] = ((pathL >> LANE) & 1) && ml != 1;
+                })
+            }
+            const uint64_t seqMask = BALLOT(isSeq[I_]);
+            const int cnt = __builtin_popcountll(seqMask);
+            if (cnt) {
+                if (nseq + cnt > 64) { if (!flush()) return 0; }
+                const int base = nseq, ip0 = ip; const bool directL = direct; const int curL = cur, bestL = bestMl;
+                LANES({
+                    if (isSeq[I_]) {
+                        const int k = base + __builtin_popcountll(seqMask & ((1ull << LANE) - 1));
+                        const int ml = (directL && LANE == curL) ? bestL : (int)(nv[I_] >> 16);
+                        w.seq[k] = (uint64_t)(uint32_t)(ip0 + LANE) | ((uint64_t)(uint32_t)ml << 23) | ((uint64_t)(nv[I_] & 0xFFFFu) << 46);
+                    }
+                })
+                nseq += cnt;
+                const int hi = 63 - __builtin_clzll(seqMask);
+                const int mlHi = (direct && hi == cur) ? bestMl : (int)(RL(nv, hi) >> 16);
+                pendEnd = ip + hi + mlHi;
+                if (nseq == 64) { if (!flush()) return 0; }
+            }
+            ip += direct ? cur + bestMl : last;
+        } else {
+        {   // reverse traversal: mark the chosen path (:2026-2046)
+                // (a direct long match may not fit the 16 bits of length: it is the path's last sequence, bestMl is kept aside)
+                int cand = cur; uint32_t sel = ((uint32_t)bestMl << 16) | (uint32_t)(bestOff & 0xFFFF);
+                for (;;) {
+                    const uint32_t nx = UNI(HC12_MLOFF(cand));
+                    { const int candL = cand; const uint32_t selL = sel; LANES({ if (LANE == 0) { if (candL < w.nl) w.ent[candL].mloff = selL; else w.gmloff[candL - w.nl] = selL; } }) }
+                    LDS_ORDER();
+                    sel = nx;
+                    const int nml = (int)(nx >> 16);
+                    if (nml > cand) break;
+                    cand -= nml;
+                }
+            }
+            {   // record the sequences in order (:2048-2064)
+                int r = 0;
+                while (r < last) {
+                    const uint32_t mo = UNI(HC12_MLOFF(r));
+                    int ml = (int)(mo >> 16); const int off = (int)(mo & 0xFFFFu);
+                    if (direct && r == cur) ml = bestMl;                                    // may not fit the table's 16 bits
+                    if (ml == 1) { ip++; r++; continue; }
+                    r += ml;
+                    if (!push_seq(ip, ml, off)) return 0;
+                    ip += ml; pendEnd = ip;
+                }
             }
         }
         PSTAT(4, STAT_NOW() - tE);

@@ -261,3 +261,39 @@ def test_gpu_host_calls_in_many_chunks(orc, monkeypatch):
     for p, r, o in zip(plain, res2, outs2):
         assert int(r) == p.size and np.array_equal(o, p)
     e.close()
+
+
+def test_gpu_dev_compress_levels_and_trim(ref, orc):
+    """plz4hip_dev_compress (raw blocks on the device) at level 1, a hash-chain level and level 12; plz4hip_ctx_trim gives the
+    staging and HC workspaces back and the ctx keeps working."""
+    import ctypes as C
+    import torch
+    from plz4_amd._native import Engine
+    e = Engine(0)
+    dev = torch.device("cuda:0")
+    n = 300000
+    srcs = [synth.text(n, seed=3), synth.make("M", n, 65536), np.zeros(n, np.uint8), synth.text(4097, seed=4)]
+    stride = 1 << 19
+    cap = orc.bound(n)
+    d_src = torch.zeros(len(srcs) * stride, dtype=torch.uint8, device=dev)
+    for i, s in enumerate(srcs):
+        d_src[i * stride:i * stride + s.size] = torch.from_numpy(s).to(dev)
+    d_len = torch.tensor([s.size for s in srcs], dtype=torch.int32, device=dev)
+    d_cap = torch.full((len(srcs),), cap, dtype=torch.int32, device=dev)
+    for lvl in (1, 5, 12):
+        d_dst = torch.zeros(len(srcs) * stride, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(len(srcs), dtype=torch.int32, device=dev)
+        e._chk(e.L.plz4hip_dev_compress(e.h, len(srcs), d_src.data_ptr(), stride, d_len.data_ptr(), d_dst.data_ptr(), stride,
+                                        d_cap.data_ptr(), lvl, n, d_res.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        res = d_res.cpu().numpy(); out = d_dst.cpu().numpy()
+        for i, s in enumerate(srcs):
+            want_n, want = (orc.compress_fast(s, cap) if lvl == 1 else ref.compress_hc(s, cap, lvl))
+            assert int(res[i]) == want_n and np.array_equal(out[i * stride:i * stride + want_n], want[:want_n]), (lvl, i)
+        if lvl == 5:
+            e.trim()                                                             # HC workspace gone; the next call allocates again
+    recs = e.encode_records(srcs, 1 << 19, True)
+    e.trim()
+    recs2 = e.encode_records(srcs, 1 << 19, True)
+    assert all(np.array_equal(a, b) for a, b in zip(recs, recs2))
+    e.close()
