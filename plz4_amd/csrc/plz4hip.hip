@@ -750,7 +750,7 @@ struct plz4hip_ctx {
     HostSlot     slot[kSlots];
     uint8_t*     d_hc = nullptr;   int hcWaves = 0;     // HC workspace, one slot per resident HC wave (allocated on first use)
     // level 12 in three phases: chain + search results of one group of blocks, the parser's table overflow, an error flag
-    uint8_t*     d_h12 = nullptr;  size_t h12Bytes = 0;  int h12ParseWaves = 0;
+    uint8_t*     d_h12 = nullptr;  size_t h12Bytes = 0;  int h12ParseWaves = 0;  size_t h12ErrOff = 0;
     // Both HC workspaces belong to one job at a time: the stream of the last HC job and an event recorded behind it; an HC
     // job on another stream waits for that event on the device (no host block).
     hipEvent_t   hcDone = nullptr; hipStream_t hcStream = nullptr; bool hcPending = false;
@@ -919,19 +919,21 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc12_parse, 64, 0) != hipSuccess || per < 1) per = 8;
         c->h12ParseWaves = c->cus * per;
     }
-    pl->offRank = round_up((size_t)pl->group * (size_t)pl->chainStride * 2, 256);
+    // [0, 256): the error flag (zeroed when the workspace is allocated, sticky); the chains start behind it
+    pl->offRank = 256 + round_up((size_t)pl->group * (size_t)pl->chainStride * 2, 256);
     pl->offList = pl->offRank + round_up((size_t)pl->group * (size_t)pl->chainStride * 4, 256);
     pl->offOffsets = pl->offList + round_up((size_t)pl->group * ((size_t)pl->chainStride + 8) * 4, 256);
     pl->offF = pl->offOffsets + round_up((size_t)pl->group * (size_t)kHcHashEntries * 4, 256);
     pl->offWs = pl->offF + round_up((size_t)pl->group * (size_t)pl->fStride * 8, 256);
-    pl->offErr = pl->offWs + round_up((size_t)c->h12ParseWaves * kHc12WsGlobalBytes, 256);
-    pl->total = pl->offErr + 256;
+    pl->offErr = 0;
+    pl->total = pl->offWs + round_up((size_t)c->h12ParseWaves * kHc12WsGlobalBytes, 256);
     if (pl->total > c->h12Bytes) {
         if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));          // nothing may still use the old workspace
         if (c->d_h12) hipFree(c->d_h12);
         c->d_h12 = nullptr; c->h12Bytes = 0;
         if (hipMalloc((void**)&c->d_h12, pl->total) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "level-12 workspace");
         c->h12Bytes = pl->total;
+        HIPCHK(c, hipMemset(c->d_h12, 0, 256));
     }
     return PLZ4HIP_OK;
 }
@@ -947,16 +949,15 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     if (use_h12(a, maxLen)) {
         H12Plan pl;
         if (int rc = plan_h12(c, nb, maxLen, &pl)) return rc;
-        a.h12Chain = (uint16_t*)c->d_h12; a.h12ChainStride = pl.chainStride;
+        a.h12Chain = (uint16_t*)(c->d_h12 + 256); a.h12ChainStride = pl.chainStride;
         a.h12Rank = (uint32_t*)(c->d_h12 + pl.offRank); a.h12List = (uint32_t*)(c->d_h12 + pl.offList);
         a.h12Offsets = (uint32_t*)(c->d_h12 + pl.offOffsets);
         a.h12F = (Hc12F*)(c->d_h12 + pl.offF); a.h12FStride = pl.fStride;
-        a.h12Ws = c->d_h12 + pl.offWs; a.h12Err = (int32_t*)(c->d_h12 + pl.offErr);
+        a.h12Ws = c->d_h12 + pl.offWs; a.h12Err = (int32_t*)(c->d_h12 + pl.offErr); c->h12ErrOff = pl.offErr;
         a.rawMode = rawMode;
         a.h12Gather = 12; a.h12Idle = 16;
         if (const char* v = getenv("PLZ4HIP_HC12_GATHER")) a.h12Gather = atoi(v);
         if (const char* v = getenv("PLZ4HIP_HC12_IDLE")) a.h12Idle = atoi(v);
-        HIPCHK(c, hipMemsetAsync(a.h12Err, 0, 4, s));
         const int nGroups = (nb + pl.group - 1) / pl.group;
         const int per = (nb + nGroups - 1) / nGroups;                     // groups of equal size (<= pl.group)
         for (int g0 = 0; g0 < nb; g0 += per) {
@@ -1438,6 +1439,13 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     }
     for (; retired < nChunks && rc == PLZ4HIP_OK; ++retired) rc = retire(retired);
     if (rc != PLZ4HIP_OK) for (int i = 0; i < nSlots; ++i) if (c->slot[i].s) hipStreamSynchronize(c->slot[i].s);   // nothing left in flight
+    if (rc == PLZ4HIP_OK && hcMode && c->d_h12 && dj->level >= 12) {
+        // the level-12 search kernel bounds its spins and raises this flag if it ever gives up (never seen): an engine failure,
+        // not a result
+        int32_t flag = 0;
+        HIPCHK(c, hipMemcpy(&flag, c->d_h12 + c->h12ErrOff, 4, hipMemcpyDeviceToHost));
+        if (flag) return fail(c, PLZ4HIP_E_DEVICE, "level-12 search kernel gave up (spin guard)");
+    }
     return rc;
 }
 
