@@ -169,6 +169,20 @@ def test_emu_hc12_search_as_the_kernel_runs_it(emu):
         assert emu.hc12_search_check(src) == 0, src.size
 
 
+def test_emu_hc12_other_atomic_order(ref, emu):
+    """hc12_build_lists takes list slots and previous positions with LDS atomics and expects same-slot lanes to resolve in lane
+    order; the emulation can resolve them in DEScending order: the kernel must detect that and put it right (same bytes out)."""
+    emu.set_descending(True)
+    try:
+        for src in (synth.text(40000), np.zeros(5000, np.uint8), synth.make("M", 120000, 65536)[60000:100000], np.tile(np.arange(7, dtype=np.uint8), 3000)):
+            a, da = ref.compress_hc(src, src.size, 12)
+            b, db = emu.compress_hc12(src, src.size)
+            assert a == b and np.array_equal(da, db), src.size
+            assert emu.hc12_search_check(src) == 0
+    finally:
+        emu.set_descending(False)
+
+
 def test_emu_hc12_golden_digests(emu):
     for b, blk in _golden_blocks():
         if b["level"] == 12 and b["bsz"] <= (64 << 10):
