@@ -370,6 +370,9 @@ struct Hc12Walk {
             hc12_ld8(t.list + ((int)cursor - 8), pe);
             pePending = 1;
         }
+        // Two rounds of up to four candidates per trip (a fetch brings eight entries): the second round costs the lanes that are
+        // still walking only the candidate tests themselves, not another trip through the wave's phase scheduling.
+        for (int round = 0; round < 2; ++round) {
         // the next candidates and their links, as far as the fetched entries go: candidate k needs entry k
         const int can = (listEnded || nb >= 4) ? 4 : nb;
         uint32_t m[5], d[4], t16[4], m32[4];
@@ -416,6 +419,8 @@ struct Hc12Walk {
         attempts -= can;
         mi = can == 1 ? m[1] : (can == 2 ? m[2] : (can == 3 ? m[3] : m[4]));
         if (nb >= can) pop(can); else { nb = 0; listEnded = 1; }
+        if (nb == 0 && !listEnded) break;                 // the next entries are on their way
+        }
         return false;
     }
     DEVM bool is_near() const { return longest <= 60; }
