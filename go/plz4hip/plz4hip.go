@@ -438,3 +438,49 @@ func toInts(v []C.int32_t) []int {
 	}
 	return out
 }
+
+
+// ---- streaming content checksum on the device (section B'' of plz4hip.h): xxh32.XXHZero kept by the engine.  While a stream is
+// attached to a ctx, EncodeRecords[Ex] / DecodeRecords[Ex] on that ctx also write the plaintext of their blocks into it, in order
+// (async/hash.go:99-111 without the plaintext passing through a Go hasher).
+type HashStream struct {
+	c *Ctx
+	p *C.plz4hip_xxh32_stream
+}
+
+func (c *Ctx) NewHashStream() (*HashStream, error) {
+	h := &HashStream{c: c}
+	if rc := C.plz4hip_xxh32_stream_create(c.p, &h.p); rc != C.PLZ4HIP_OK {
+		return nil, c.engineErr(rc)
+	}
+	return h, nil
+}
+func (h *HashStream) Close()        { C.plz4hip_xxh32_stream_destroy(h.c.p, h.p); h.p = nil }
+func (h *HashStream) Reset() error  { return h.c.chk(C.plz4hip_xxh32_stream_reset(h.c.p, h.p)) }
+func (h *HashStream) Attach() error { return h.c.chk(C.plz4hip_ctx_set_content_hash(h.c.p, h.p)) }
+func (h *HashStream) Detach() error { return h.c.chk(C.plz4hip_ctx_set_content_hash(h.c.p, nil)) }
+func (h *HashStream) Write(b []byte) (int, error) { // io.Writer over host bytes (what is not an encode / decode call's plaintext)
+	if len(b) == 0 {
+		return 0, nil
+	}
+	var pin runtime.Pinner
+	pin.Pin(&b[0])
+	defer pin.Unpin()
+	if rc := C.plz4hip_xxh32_stream_update(h.c.p, h.p, unsafe.Pointer(&b[0]), C.int64_t(len(b))); rc != C.PLZ4HIP_OK {
+		return 0, h.c.engineErr(rc)
+	}
+	return len(b), nil
+}
+func (h *HashStream) Sum32() (uint32, error) {
+	var out C.uint32_t
+	if rc := C.plz4hip_xxh32_stream_sum(h.c.p, h.p, &out); rc != C.PLZ4HIP_OK {
+		return 0, h.c.engineErr(rc)
+	}
+	return uint32(out), nil
+}
+func (c *Ctx) chk(rc C.int) error {
+	if rc != C.PLZ4HIP_OK {
+		return c.engineErr(rc)
+	}
+	return nil
+}
