@@ -144,6 +144,7 @@ struct HipEngine : BlockEngine {
     void  HashFree(void* h) override { plz4hip_xxh32_stream_destroy(ctx, (plz4hip_xxh32_stream*)h); }
     int   HashAttach(void* h) override { return plz4hip_ctx_set_content_hash(ctx, (plz4hip_xxh32_stream*)h); }
     int   HashSum(void* h, uint32_t* out) override { return plz4hip_xxh32_stream_sum(ctx, (plz4hip_xxh32_stream*)h, out); }
+    int   HashReset(void* h) override { return plz4hip_xxh32_stream_reset(ctx, (plz4hip_xxh32_stream*)h); }
 };
 struct VtEngine : BlockEngine {
     EngineVTable vt;
@@ -424,6 +425,7 @@ class ReaderImpl : public Reader {
     // frame state
     bool inBody = false; HeaderT hdr; int bsz = 0; bool blkCheck = false, srcCheck = false, hashing = false;
     Xxh32Stream hasher; uint64_t contentSz = 0; uint32_t srcSum = 0;
+    void* devHash = nullptr;                 // the engine's content-checksum stream (null: hash on the host)
     int64_t srcPos = 0, dstPos = 0;
     // decoded blocks ready for delivery + the error that follows them
     struct Out { Bytes data; int nRead; };
@@ -504,6 +506,10 @@ class ReaderImpl : public Reader {
         srcCheck = ((hdr.Flags >> 2) & 1) && !clrContentChecksum;
         hashing = srcCheck && o.ContentChecksum;
         hasher.Reset(); contentSz = 0; inBody = true;
+        if (hashing) {                                       // the engine keeps the content checksum if it can (one stream per reader)
+            if (!devHash) devHash = eng.HashNew();
+            else if (eng.HashReset(devHash) != 0) { eng.HashFree(devHash); devHash = nullptr; }
+        }
         ready.clear(); pendingErr = Error(); pendingRead = 0; dstBlk.clear(); dstOff = 0;
         return Error();
     }
@@ -536,6 +542,7 @@ class ReaderImpl : public Reader {
         std::vector<Bytes> outs(n);
         for (int i = 0; i < n; i++) { rp[i] = recs[i].data(); rl_[i] = (int32_t)recs[i].size(); outs[i].resize((size_t)bsz + 8); dp[i] = outs[i].data(); }
         int rc;
+        struct Attach { BlockEngine& e; void* h; Attach(BlockEngine& e_, void* h_) : e(e_), h(h_) { if (h) e.HashAttach(h); } ~Attach() { if (h) e.HashAttach(nullptr); } } at(eng, hashing ? devHash : nullptr);
         if (linked) rc = eng.DecodeRecordsEx(n, rp.data(), rl_.data(), bsz, blkCheck ? 1 : 0, 1, nullptr, window.data(), &windowLen, dp.data(), res.data(), st.data());
         else if (dictH) rc = eng.DecodeRecordsEx(n, rp.data(), rl_.data(), bsz, blkCheck ? 1 : 0, 0, dictH, nullptr, nullptr, dp.data(), res.data(), st.data());
         else rc = eng.DecodeRecords(n, rp.data(), rl_.data(), bsz, blkCheck ? 1 : 0, dp.data(), res.data(), st.data());
@@ -560,7 +567,7 @@ class ReaderImpl : public Reader {
         if (ready.empty() && !pendingErr) fill();
         if (!ready.empty()) {
             Out o2 = std::move(ready.front()); ready.pop_front();
-            if (hashing) hasher.Write(o2.data.data(), o2.data.size());
+            if (hashing && !devHash) hasher.Write(o2.data.data(), o2.data.size());
             dstBlk = std::move(o2.data);
             progress(srcPos, dstPos);
             srcPos += o2.nRead; dstPos += (int64_t)dstBlk.size(); contentSz += dstBlk.size();
@@ -569,7 +576,12 @@ class ReaderImpl : public Reader {
         Error e = pendingErr; pendingErr = Error();
         progress(srcPos, dstPos);
         srcPos += pendingRead; pendingRead = 0;
-        if (e.code == EndMark && hashing) { if (hasher.total == 0) hasher.Reset(); if (hasher.Sum32() != srcSum) e = E(ErrContentHash, true); }
+        if (e.code == EndMark && hashing) {
+            uint32_t sum = 0;
+            if (devHash) { if (eng.HashSum(devHash, &sum) != 0) return E(ErrEngine); }
+            else { if (hasher.total == 0) hasher.Reset(); sum = hasher.Sum32(); }
+            if (sum != srcSum) e = E(ErrContentHash, true);
+        }
         return e;
     }
     Error handleEndMark()                                                                  // rdr.go:91-101
@@ -582,7 +594,7 @@ class ReaderImpl : public Reader {
 
 public:
     ReaderImpl(Source& r, BlockEngine& e, const Options& op) : rd(r), eng(e), o(op) {}
-    ~ReaderImpl() override { if (dictH) eng.DictDestroy(dictH); }
+    ~ReaderImpl() override { if (dictH) eng.DictDestroy(dictH); if (devHash) eng.HashFree(devHash); }
     Error Read(uint8_t* dst, size_t n, size_t* got) override
     {
         *got = 0;

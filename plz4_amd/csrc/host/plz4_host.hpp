@@ -93,12 +93,14 @@ struct BlockEngine {
     virtual int DecodeRecordsEx(int, const void* const*, const int32_t*, int, int, int /*linked*/, void* /*dict*/,
                                 void* /*window*/, int* /*windowLen*/, void* const*, int32_t*, int32_t*) { return -4; }
     // streaming content checksum kept by the engine (xxh32.XXHZero, async/hash.go:99-111): while a stream is set with
-    // HashAttach, EncodeRecords[Ex] also writes the plaintext of its blocks, in order, into it.  Default: the engine has none
+    // HashAttach, EncodeRecords[Ex] also writes the plaintext of its blocks, in order, into it, and DecodeRecords[Ex] the plaintext
+    // it produces.  Default: the engine has none
     // (HashNew returns null) and the writer hashes on the host.
     virtual void* HashNew() { return nullptr; }
     virtual void  HashFree(void* /*h*/) {}
     virtual int   HashAttach(void* /*h or null*/) { return -4; }
     virtual int   HashSum(void* /*h*/, uint32_t* /*out*/) { return -4; }
+    virtual int   HashReset(void* /*h*/) { return -4; }
 };
 std::unique_ptr<BlockEngine> NewHipEngine(int device, int* rc);     // the product engine (plz4hip_ctx)
 
