@@ -123,6 +123,38 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
     }
 }
 
+// The chain alone (HcWork::pre for levels 3..11): one pass, `tab` = 32768 x uint32 of LDS (128 KiB): last position + 1 per hash.
+DEV void hc12_build_chain(const uint8_t* __restrict__ src, const int n, uint16_t* __restrict__ chain, const int nPad, uint32_t* tab)
+{
+    LANES({ for (int i = LANE; i < kHcHashEntries; i += 64) tab[i] = 0u; })
+    LDS_FENCE();
+    const int nIns = n >= 4 ? n - 3 : 0;
+    for (int base = 0; base < nPad; base += 64) {
+        LV(uint32_t, h); LV(uint32_t, prev); LV(int, act);
+        LANES({
+            const int p = base + LANE;
+            act[I_] = p < nIns; h[I_] = 0; prev[I_] = 0;
+            if (act[I_]) { h[I_] = hc12_hash(ld32u(src + p)); prev[I_] = lds_max_rtn(&tab[h[I_]], (uint32_t)p + 1u); }
+        })
+        LDS_FENCE();
+        if (BALLOT(act[I_] && prev[I_] > (uint32_t)(base + LANE))) {      // another resolution order: see hc12_build_lists
+            LV(uint32_t, gmin); LV(uint32_t, near);
+            LANES({ gmin[I_] = prev[I_]; near[I_] = 0; })
+            for (int l = 0; l < 64; ++l) {
+                const uint32_t hl = RL(h, l), pl = RL(prev, l); const int al = RL(act, l);
+                LANES({ if (al && act[I_] && h[I_] == hl) { if (pl < gmin[I_]) gmin[I_] = pl; if (l < LANE) near[I_] = (uint32_t)(base + l) + 1u; } })
+            }
+            LANES({ prev[I_] = near[I_] ? near[I_] : gmin[I_]; })
+        }
+        LANES({
+            const int p = base + LANE;
+            uint32_t d = 0;
+            if (act[I_] && prev[I_]) { const uint32_t dist = (uint32_t)p + 1u - prev[I_]; d = dist <= 65535u ? dist : 0u; }
+            chain[p] = (uint16_t)d;
+        })
+    }
+}
+
 // ------------------------------------------------------------------------------------------ phase 2: F(p), one lane per position
 // Chain accessors: ch(q) = the stored value of position q.
 struct Hc12Flat { const uint16_t* c; DEVM uint32_t operator()(uint32_t q) const { return c[q]; } };

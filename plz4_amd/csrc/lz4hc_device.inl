@@ -37,6 +37,12 @@ struct HcWork {
     uint32_t* hash;     // 32768 entries  (LZ4HC_HASHTABLESIZE, lz4hc.h:226-227)
     uint16_t* chain;    // 65536 entries  (LZ4HC_MAXD, lz4hc.h:222-223)
     HcOpt*    opt;      // LZ4_OPT_NUM + 3 entries (lz4hc.c:76, :1836-1841)
+    // Independent blocks without dictionary: when a position is searched every position below it has been inserted
+    // (LZ4HC_Insert runs up to it, :914), so the chain is a function of the data alone and can be built for the whole block up
+    // front (hc12_build_lists, lz4hc12_device.inl): pre[q] = distance from q to the previous position with q's hash, 0 = none
+    // within 65535.  With `pre` set the parsers neither reset nor fill the two tables above (4 M dependent table updates per
+    // 4 MiB block): the head candidate of a search is pos - pre[pos], a chain link is pre[] again.
+    const uint16_t* pre;
 };
 enum : int { kHcHashEntries = 32768, kHcChainEntries = 65536, kHcOptNum = 4096, kHcTrailing = 3,
              kHcWorkBytes = kHcHashEntries * 4 + kHcChainEntries * 2 + (kHcOptNum + kHcTrailing + 1) * 16 };
@@ -74,9 +80,15 @@ DEV int hc_count(const uint8_t* a, const uint8_t* b, const uint8_t* limit)
 }
 
 // LZ4HC_Insert (lz4hc.c:781-802): chain every position below `pos`
+DEV uint32_t hc_link(const HcState& s, uint32_t idx)       // chain table entry of index idx (lz4hc.c:228 DELTANEXTU16)
+{
+    if (s.w.pre) { const uint32_t d = s.w.pre[idx - kHcBase]; return d ? d : 65535u; }
+    return s.w.chain[idx & 0xFFFFu];
+}
 DEV void hc_insert(HcState& s, int pos)
 {
     const uint32_t target = (uint32_t)pos + kHcBase;
+    if (s.w.pre) { s.nextToUpdate = target; return; }
     for (uint32_t idx = s.nextToUpdate; idx < target; ++idx) {
         const uint32_t h = hc_hash(s.src + (idx - kHcBase));
         uint32_t delta = idx - s.w.hash[h];
@@ -157,13 +169,13 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
     size_t srcPatternLength = 0;
 
     hc_insert(s, pos);
-    uint32_t mi = s.w.hash[hc_hash(ip)];
+    uint32_t mi = s.w.pre ? (s.w.pre[pos] ? ipIndex - s.w.pre[pos] : 0u) : s.w.hash[hc_hash(ip)];
 
     while (mi >= lowest && attempts > 0) {
         int mlen = 0;
         attempts--;
         // the chain link of this candidate is requested together with its bytes: one memory round trip per hop, not two
-        const uint32_t dn0 = s.w.chain[mi & 0xFFFFu];
+        const uint32_t dn0 = hc_link(s, mi);
         {
             const uint8_t* const mp = src + (mi - kHcBase);
             const uint32_t m32 = ld32u(mp);       // requested with the 2-byte probe and the chain link, whether or not it gets looked at
@@ -192,9 +204,9 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
                 // the links of the first 64 positions of the match in one load (lane l: position l) instead of one memory
                 // round trip per position; a longer match goes on with single loads
                 LV(uint32_t, links);
-                { const uint32_t mi0 = mi; LANES({ links[I_] = (LANE < end) ? (uint32_t)s.w.chain[(mi0 + (uint32_t)LANE) & 0xFFFFu] : 0u; }) }
+                { const uint32_t mi0 = mi; LANES({ links[I_] = (LANE < end) ? hc_link(s, mi0 + (uint32_t)LANE) : 0u; }) }
                 for (int p2 = 0; p2 < end; p2 += step) {
-                    const uint32_t cd = p2 < 64 ? RL(links, p2) : (uint32_t)s.w.chain[(mi + (uint32_t)p2) & 0xFFFFu];
+                    const uint32_t cd = p2 < 64 ? RL(links, p2) : hc_link(s, mi + (uint32_t)p2);
                     step = (accel++ >> 4);
                     if (cd > distNext) { distNext = cd; chainPos = (uint32_t)p2; accel = 1 << 4; }
                 }
@@ -240,7 +252,7 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
                                         longest = (int)maxML;
                                         offset = (int)(ipIndex - mi);
                                     }
-                                    const uint32_t dp = s.w.chain[mi & 0xFFFFu];
+                                    const uint32_t dp = hc_link(s, mi);
                                     if (dp > mi) break;
                                     mi -= dp;
                                 }
@@ -251,7 +263,7 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
                 }
             }
         }
-        mi -= chainPos == 0 ? dn0 : s.w.chain[(mi + chainPos) & 0xFFFFu];                        // :1065
+        mi -= chainPos == 0 ? dn0 : hc_link(s, mi + chainPos);                                   // :1065
     }
     if (kD && s.d.mode == kHcCtx && attempts > 0 && within) {                                          // usingDictCtxHc, :1069-1098
         const uint32_t dictEnd = kHcBase + (uint32_t)s.d.len;        // the context's end index: its own indices start at 64 KiB
@@ -356,6 +368,7 @@ DEV uint32_t mid_hash8(const uint8_t* p) { return (uint32_t)(((ld64u(p) << 8) * 
 // tables of HcDict for kHcCtx (pfx = dictionary length).
 DEV void hc_prime(HcState& s, int level)
 {
+    if (s.w.pre && level > 2) { s.nextToUpdate = kHcBase + (uint32_t)s.pfx; return; }    // (independent block, no segment: nothing to prime)
     hc_reset_tables(s.w);
     s.nextToUpdate = kHcBase;
     const int size = s.pfx;

@@ -286,7 +286,7 @@ __device__ __forceinline__ HcWork hc_work_of(const CodecArgs& a)
 {
     uint8_t* ws = a.hcWork + (size_t)blockIdx.x * kHcWorkBytes;
     HcWork w; w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + kHcHashEntries * 4);
-    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2);
+    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2); w.pre = nullptr;
     return w;
 }
 // How block i of an HC call is primed: clz4.StreamCtxHC (clz4.go:181-209, dictionary + independent blocks),
@@ -312,6 +312,12 @@ __device__ __forceinline__ HcDict hc_dict_of(const CodecArgs& a, int i, int n, c
     }
     return d;
 }
+// independent block i without dictionary: its chain was built up front (k_hc_chain) when the call's launcher found room for it
+__device__ __forceinline__ HcWork hc_with_pre(HcWork w, const CodecArgs& a, int i)
+{
+    w.pre = a.h12Chain ? a.h12Chain + (int64_t)i * a.h12ChainStride : nullptr;
+    return w;
+}
 __global__ __launch_bounds__(64) void k_encode_raw_hc(CodecArgs a)
 {
     const HcWork w = hc_work_of(a);
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(64) void k_encode_raw_hc(CodecArgs a)
         const uint8_t* s = a.src + (int64_t)i * a.srcStride;
         int r;
         if (dictMode) r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, w, hc_dict_of(a, i, n, s, true));
-        else          r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, w);
+        else          r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, hc_with_pre(w, a, i));
         if ((threadIdx.x & 63u) == 0) a.result[i] = r;
     }
 }
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
         uint8_t*       rec = a.dst + (int64_t)i * a.dstStride;
         int c;                                                           // capacity == bsz (blk.go:73); indie.go:80-88
         if (exMode) c = hc_compress(s, n, rec + 4, a.bsz, a.level, w, hc_dict_of(a, i, n, s, false));
-        else        c = hc_compress(s, n, rec + 4, a.bsz, a.level, w);
+        else        c = hc_compress(s, n, rec + 4, a.bsz, a.level, hc_with_pre(w, a, i));
         uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
         WAVE_FENCE();
         if (c == 0) { wave_copy(rec + 4, s, n); c = n; word = 0x80000000u | ((uint32_t)n & 0x7FFFFFFFu); }
@@ -403,6 +409,18 @@ __global__ __launch_bounds__(64) void k_hc12_chain(CodecArgs a)
         hc12_build_lists(a.src + (int64_t)i * a.srcStride, n, a.h12Offsets + (size_t)g * kHcHashEntries,
                          a.h12Chain + (int64_t)g * a.h12ChainStride, a.h12Rank + (int64_t)g * a.h12ChainStride,
                          a.h12List + (int64_t)g * (a.h12ChainStride + 8) + 8, nPad, lastT, curT);
+    }
+}
+
+// The chain alone, for levels 3..11 (HcWork::pre): one pass per block with the whole 128 KiB table in LDS.
+__global__ __launch_bounds__(64) void k_hc_chain(CodecArgs a)
+{
+    __shared__ uint32_t tab[kHcHashEntries];
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int n = block_len(a, i);
+        int nPad = (n + 1 + 1023) & ~1023;
+        if (nPad > a.h12ChainStride) nPad = (int)a.h12ChainStride;
+        hc12_build_chain(a.src + (int64_t)i * a.srcStride, n, a.h12Chain + (int64_t)i * a.h12ChainStride, nPad, tab);
     }
 }
 
@@ -611,7 +629,7 @@ __global__ __launch_bounds__(64) void k_hc_dict_prime(const uint8_t* dict, int l
 {
     uint8_t* ws = tabs + (size_t)blockIdx.x * kHcWorkBytes;
     HcWork w; w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + kHcHashEntries * 4);
-    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2);
+    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2); w.pre = nullptr;
     hc_prime_dict(dict, len, blockIdx.x == 0 ? 2 : 3, w);
 }
 
@@ -976,6 +994,31 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     } else {
         if (int rc = ensure_hc(c)) return rc;
         a.hcWork = c->d_hc; a.nBlocks = nb;
+        a.h12Chain = nullptr;
+        if (a.level >= 3 && !a.hcEx && maxLen >= 4096 && getenv("PLZ4HIP_HC_PRE_OFF") == nullptr) {
+            // levels 3..11, independent blocks: the chain of every block of the call built up front (2 B per position), if it
+            // fits the budget of plan_h12; the parsers then run without their 4 M dependent table updates per 4 MiB block
+            const int64_t stride = (int64_t)round_up((size_t)maxLen + 1, 1024);
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
+            const size_t need = 256 + (size_t)nb * (size_t)stride * 2 + 64;
+            size_t budget = (freeB + c->h12Bytes) / 2;
+            if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
+            if (need <= budget) {
+                if (need > c->h12Bytes) {
+                    if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));
+                    if (c->d_h12) hipFree(c->d_h12);
+                    c->d_h12 = nullptr; c->h12Bytes = 0;
+                    if (hipMalloc((void**)&c->d_h12, need) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "HC chain workspace");
+                    c->h12Bytes = need;
+                    HIPCHK(c, hipMemset(c->d_h12, 0, 256));
+                }
+                a.h12Chain = (uint16_t*)(c->d_h12 + 256); a.h12ChainStride = stride; a.blk0 = 0;
+                a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+                hipLaunchKernelGGL(k_hc_chain, dim3(grid_for(nb, c->cus)), dim3(64), 0, s, a);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
         a.queue = next_queue(c, s, &e); HIPCHK(c, e);
         if (rawMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
         else         hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);

@@ -51,7 +51,7 @@ int emu_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level)
     if (!ws) ws = (uint8_t*)malloc(plz4::kHcWorkBytes);
     plz4::HcWork w;
     w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + plz4::kHcHashEntries * 4);
-    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2);
+    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2); w.pre = nullptr;
     return plz4::hc_compress(src, n, dst, cap, level, w);
 }
 
@@ -59,7 +59,7 @@ static plz4::HcWork emu_hc_work(uint8_t* ws)
 {
     plz4::HcWork w;
     w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + plz4::kHcHashEntries * 4);
-    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2);
+    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2); w.pre = nullptr;
     return w;
 }
 
@@ -219,4 +219,23 @@ extern "C" int emu_hc12_search_check(const uint8_t* src, int n, long* trips)
         if (a.len > kHc12Sufficient + 8 && p + a.len - kHc12Sufficient > skipUntil) skipUntil = p + a.len - kHc12Sufficient;
     }
     return bad;
+}
+
+// HC levels 3..11 on the chain built up front (HcWork::pre): the parsers of lz4hc_device.inl without their own table inserts.
+extern "C" int emu_compress_hc_pre(const uint8_t* src, int n, uint8_t* dst, int cap, int level)
+{
+    using namespace plz4;
+    const int nPad = ((n > 0 ? n : 0) + 1 + 1023) / 1024 * 1024;
+    uint8_t* padded = (uint8_t*)calloc((size_t)(n > 0 ? n : 0) + 64, 1);
+    if (n > 0) memcpy(padded, src, (size_t)n);
+    uint16_t* chain = (uint16_t*)malloc((size_t)nPad * 2 + 64);
+    uint32_t* tab = (uint32_t*)malloc((size_t)kHcHashEntries * 4);
+    hc12_build_chain(padded, n, chain, nPad, tab);
+    static thread_local uint8_t* ws = nullptr;
+    if (!ws) ws = (uint8_t*)malloc(kHcWorkBytes);
+    HcWork w = emu_hc_work(ws);
+    w.pre = chain;
+    const int r = hc_compress(padded, n, dst, cap, level, w);
+    free(tab); free(chain); free(padded);
+    return r;
 }

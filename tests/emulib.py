@@ -104,3 +104,11 @@ class Emu:
         self.L.emu_hc12_search_check.restype = C.c_int
         self.L.emu_hc12_search_check.argtypes = [u8p, C.c_int, C.c_void_p]
         return int(self.L.emu_hc12_search_check(_ptr(src) if src.size else C.cast(None, u8p), src.size, None))
+
+    def compress_hc_pre(self, src, cap, level):
+        """HC levels 3..11 with the chain built up front (what the kernels run for independent blocks without dictionary)."""
+        self.L.emu_compress_hc_pre.restype = C.c_int
+        self.L.emu_compress_hc_pre.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int]
+        dst = np.empty(max(cap, 1) + 64, dtype=np.uint8)
+        r = int(self.L.emu_compress_hc_pre(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, level))
+        return r, dst[:max(r, 0)]

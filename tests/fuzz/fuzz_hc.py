@@ -46,6 +46,12 @@ def main(iters=400, seed=7):
                 if a != b or not np.array_equal(da, db):
                     bad += 1
                     print("MISMATCH", it, kind, n, lvl, cap, a, b)
+                if 3 <= lvl <= 11:                       # the same parsers on the chain built up front (HcWork::pre: what the kernels run)
+                    b, db = emu.compress_hc_pre(src, cap, lvl)
+                    tot += 1
+                    if a != b or not np.array_equal(da, db):
+                        bad += 1
+                        print("MISMATCH pre", it, kind, n, lvl, cap, a, b)
                 if lvl == 12:                            # the three-phase level-12 path (lz4hc12_device.inl): chain, per-position search, parser
                     for nc, nl in ((0, 1024), (5, 48)):  # nc: positions left to the parser's own search; nl: price-table entries in "LDS"
                         b, db = emu.compress_hc12(src, cap, nc, nl)

@@ -137,6 +137,21 @@ def test_gpu_hc_config4_full_size(ref, orc):
     eng.close()
 
 
+def test_emu_hc_on_the_chain_built_up_front(ref, orc, emu):
+    """Levels 3..11 as the kernels run them for independent blocks: the chain of the whole block built first (hc12_build_chain),
+    the parsers of lz4hc_device.inl reading it instead of inserting into their own tables == LZ4_compress_HC."""
+    cases = [("T", synth.text(90000)), ("Z", np.zeros(9000, np.uint8)), ("M", synth.make("M", 140000, 65536)[60000:])]
+    cases += [(n, c[:6000]) for n, c in corpus.twin_cases()[:3]]
+    cases += [c for c in corpus.small_cases() if c[1].size in (0, 5, 12, 13, 14, 40, 300, 4097)]
+    cases += [("S%d" % s, corpus.structured(30000, s)) for s in range(3)]
+    for name, src in cases:
+        for lvl in range(3, 12):
+            for cap in (orc.bound(src.size), src.size, max(src.size // 3, 1)):
+                a, da = ref.compress_hc(src, cap, lvl)
+                b, db = emu.compress_hc_pre(src, cap, lvl)
+                assert a == b and np.array_equal(da, db), (name, src.size, lvl, cap, a, b)
+
+
 # ---- level 12 in its three device phases (plz4_amd/csrc/lz4hc12_device.inl): chains + per-hash lists, F(p) per position, parser
 def test_emu_hc12_vs_reference(ref, orc, emu):
     """The three phases back to back on the CPU == LZ4_compress_HC(level 12), incl. the parser's own search for positions the
