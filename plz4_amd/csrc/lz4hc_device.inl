@@ -43,6 +43,10 @@ struct HcWork {
     // within 65535.  With `pre` set the parsers neither reset nor fill the two tables above (4 M dependent table updates per
     // 4 MiB block): the head candidate of a search is pos - pre[pos], a chain link is pre[] again.
     const uint16_t* pre;
+    // ... and with the positions of every hash laid out as one ascending run (lz4hc12_device.inl: list, rank[q] = where q sits
+    // in it, the first position of a hash flagged): the candidates of a chain are consecutive entries, so a search looks at up to
+    // 63 of them at once, one per lane (hc_find_wider_lists).  Null: one candidate after the other.
+    const uint32_t* rank; const uint32_t* list;
 };
 enum : int { kHcHashEntries = 32768, kHcChainEntries = 65536, kHcOptNum = 4096, kHcTrailing = 3,
              kHcWorkBytes = kHcHashEntries * 4 + kHcChainEntries * 2 + (kHcOptNum + kHcTrailing + 1) * 16 };
@@ -143,6 +147,141 @@ DEV int hc_count_back(const uint8_t* ip, const uint8_t* match, const uint8_t* iM
 // LZ4HC_protectDictEnd (lz4hc.c:876-879): false for the last 3 indices of the external segment
 DEV bool hc_protect(uint32_t prefixIdx, uint32_t mi) { return (uint32_t)((prefixIdx - 1u) - mi) >= 3u; }
 
+
+// LZ4HC_InsertAndGetWiderMatch for the hash-chain levels (no chain swap) on an independent block, with the chain's candidates
+// taken from `list`: up to 63 candidates per round, one per lane -- their 2-byte filter and 4-byte test (:925-932) and their
+// chain links are evaluated together, and the first lane where something happens (the tests pass: the match is measured; the
+// link is 1: pattern analysis, level 9) is handled exactly as the reference handles that candidate; the lanes below it were
+// candidates that change nothing.  One dependent memory round trip per ROUND instead of one per candidate.
+DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches, bool patternAnalysis)
+{
+    const uint8_t* const src = s.src;
+    const uint8_t* const ip = src + pos;
+    const uint8_t* const iLow = src + lowLimit;
+    const uint8_t* const iHigh = src + highLimit;
+    const uint32_t ipIndex = (uint32_t)pos + kHcBase;
+    const bool     within = kHcBase + 65536u > ipIndex;
+    const uint32_t lowest = within ? kHcBase : ipIndex - 65535u;
+    const int lookBack = pos - lowLimit;
+    const uint32_t pattern = UNI(ld32u(ip));
+    int offset = 0, sBack = 0, attempts = nbSearches, repeat = 0;
+    size_t srcPatternLength = 0;
+    HcMatch out;
+    const uint32_t head = UNI((uint32_t)s.w.pre[pos]);
+    if (head) {
+        uint32_t mi = ipIndex - head;                        // the current candidate ...
+        int cursor = (int)UNI(s.w.rank[pos]) - 1;            // ... and where it sits in the list
+        while (mi >= lowest && attempts > 0) {
+            // lane k: the candidate k places below the current one in the chain (list[cursor - k]); 64 entries are fetched so
+            // that every one of the 63 candidates knows its link (the distance to the next candidate)
+            LV(uint32_t, q); LV(int, fl); LV(int, pass); LV(int, pat);
+            {
+                const int curL = cursor;
+                LANES({ const uint32_t e = (curL - LANE >= -8) ? s.w.list[curL - LANE] : 0x80000000u; q[I_] = e & 0x7FFFFFFFu; fl[I_] = (int)(e >> 31); })
+            }
+            LV(uint32_t, qn); LV(int, fln);
+            LANES({ qn[I_] = SHFL(q, LANE + 1); fln[I_] = SHFL(fl, LANE + 1); })
+            // a candidate exists while the chain has not ended above it, it is inside the window, and attempts are left; its
+            // link is what the chain table would hold (saturated at 65535, which also ends the walk, :1065 -> :918)
+            const uint64_t ends = BALLOT(fl[I_] != 0);                          // the chain's first position sits in this lane
+            const int lastOfChain = ends ? ctz64(ends) : 64;
+            const int attL = attempts;
+            const uint64_t dead = BALLOT(LANE > lastOfChain || q[I_] + kHcBase < lowest || LANE >= attL || LANE >= 63);
+            const int nvalid = dead ? ctz64(dead) : 63;                          // lane 0 is the current candidate: valid by the loop test
+            LV(uint32_t, dn);
+            LANES({
+                const bool hasNext = LANE < lastOfChain;
+                const uint32_t d = hasNext ? q[I_] - qn[I_] : 65535u;
+                dn[I_] = d < 65535u ? d : 65535u;
+            })
+            const uint32_t ip16 = UNI((uint32_t)ld16u(iLow + longest - 1));
+            {
+                const int nv = nvalid, L = longest;
+                LANES({
+                    pass[I_] = 0; pat[I_] = 0;
+                    if (LANE < nv) {
+                        const uint8_t* mp = src + q[I_];
+                        pass[I_] = (ld16u(mp - lookBack + L - 1) == ip16) && (ld32u(mp) == pattern);
+                        pat[I_] = patternAnalysis && dn[I_] == 1u;
+                    }
+                })
+            }
+            // the walk also ends inside the round where a link is saturated: the candidate behind it is never looked at
+            const uint64_t sat = BALLOT(LANE < nvalid && dn[I_] >= 65535u);
+            const uint64_t ev = BALLOT(LANE < nvalid && (pass[I_] || pat[I_]));
+            const int kSat = sat ? ctz64(sat) : 64;
+            int k = ev ? ctz64(ev) : 64;
+            if (k > kSat) k = 64;                                                 // nothing happens before the walk ends
+            if (k == 64) {
+                // every candidate of the round changes nothing
+                const int used = kSat < nvalid ? kSat + 1 : nvalid;
+                attempts -= used;
+                if (kSat < nvalid || used > lastOfChain) break;                  // saturated link / the chain's first position consumed
+                mi = RL(q, used - 1) - RL(dn, used - 1) + kHcBase;                // the candidate below the last one looked at
+                cursor -= used;
+                continue;
+            }
+            attempts -= k + 1;
+            mi = RL(q, k) + kHcBase;
+            const uint32_t dnk = RL(dn, k);
+            const uint8_t* const mp = src + (mi - kHcBase);
+            if (RL(pass, k)) {                                                    // :933-939
+                const int back = lookBack ? hc_count_back(ip, mp, iLow, src) : 0;
+                int mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
+                mlen -= back;
+                if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
+            }
+            bool jumped = false;
+            if (RL(pat, k)) {                                                     // :989-1062 (chainPos is 0 without chain swap)
+                const uint32_t mci = mi - 1;
+                if (repeat == 0) {
+                    if (((pattern & 0xFFFFu) == (pattern >> 16)) & ((pattern & 0xFFu) == (pattern >> 24))) {
+                        repeat = 2;
+                        srcPatternLength = hc_count_pattern(ip + 4, iHigh, pattern) + 4;
+                    } else repeat = 1;
+                }
+                if (repeat == 2 && mci >= lowest) {
+                    const uint8_t* const mq = src + (mci - kHcBase);
+                    if (UNI(ld32u(mq)) == pattern) {
+                        const size_t fwd = hc_count_pattern(mq + 4, iHigh, pattern) + 4;
+                        size_t back = hc_rcount_pattern(mq, src, pattern);
+                        {   const uint32_t far = mci - (uint32_t)back;
+                            back = mci - (far > lowest ? far : lowest); }
+                        const size_t seg = back + fwd;
+                        bool stop = false;
+                        if (seg >= srcPatternLength && fwd <= srcPatternLength) {
+                            mi = mci + (uint32_t)fwd - (uint32_t)srcPatternLength;     // :1027-1036: looked at next
+                            cursor = (int)UNI(s.w.rank[mi - kHcBase]);
+                        } else {
+                            mi = mci - (uint32_t)back;                                 // :1038-1058
+                            if (lookBack == 0) {
+                                const size_t maxML = seg < srcPatternLength ? seg : srcPatternLength;
+                                if ((size_t)longest < maxML) {
+                                    if (ipIndex - mi > 65535u) stop = true;
+                                    else { longest = (int)maxML; offset = (int)(ipIndex - mi); }
+                                }
+                                if (!stop) {
+                                    const uint32_t dp = hc_link(s, mi);
+                                    if (dp > mi) stop = true;
+                                    else { const uint32_t at = mi - kHcBase; mi -= dp; cursor = (int)UNI(s.w.rank[at]) - 1; if (dp >= 65535u) stop = true; }
+                                }
+                            } else cursor = (int)UNI(s.w.rank[mi - kHcBase]);
+                        }
+                        if (stop) break;
+                        jumped = true;
+                    }
+                }
+            }
+            if (jumped) continue;
+            if (dnk >= 65535u || k >= lastOfChain) break;                          // the walk ends behind this candidate
+            mi -= dnk;                                                            // :1065
+            cursor -= k + 1;
+        }
+    }
+    out.len = longest; out.off = offset; out.back = sBack;
+    return out;
+}
+
 // LZ4HC_InsertAndGetWiderMatch (lz4hc.c:884-1104): `lowLimit` is iLowLimit (how far the match may be extended backwards),
 // `longest` the length to beat, patternAnalysis / chainSwap as in the reference.  Positions count from s.src.
 // kD = false: an independent block without a dictionary (no segment, no context): every branch for those folds away.
@@ -150,6 +289,8 @@ template <bool kD>
 DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches,
                           bool patternAnalysis, bool chainSwap)
 {
+    if (!kD && !chainSwap && s.w.list && nbSearches >= 64)      // levels 7..9 on an independent block: 63 candidates per round
+        return hc_find_wider_lists(s, pos, lowLimit, highLimit, longest, nbSearches, patternAnalysis);
     const uint8_t* const src = s.src;
     const uint8_t* const ip = src + pos;
     const uint8_t* const iLow = src + lowLimit;

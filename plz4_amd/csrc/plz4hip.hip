@@ -286,7 +286,7 @@ __device__ __forceinline__ HcWork hc_work_of(const CodecArgs& a)
 {
     uint8_t* ws = a.hcWork + (size_t)blockIdx.x * kHcWorkBytes;
     HcWork w; w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + kHcHashEntries * 4);
-    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2); w.pre = nullptr;
+    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2); w.pre = nullptr; w.rank = nullptr; w.list = nullptr;
     return w;
 }
 // How block i of an HC call is primed: clz4.StreamCtxHC (clz4.go:181-209, dictionary + independent blocks),
@@ -316,6 +316,8 @@ __device__ __forceinline__ HcDict hc_dict_of(const CodecArgs& a, int i, int n, c
 __device__ __forceinline__ HcWork hc_with_pre(HcWork w, const CodecArgs& a, int i)
 {
     w.pre = a.h12Chain ? a.h12Chain + (int64_t)i * a.h12ChainStride : nullptr;
+    w.rank = (a.h12Chain && a.h12Rank) ? a.h12Rank + (int64_t)i * a.h12ChainStride : nullptr;
+    w.list = (a.h12Chain && a.h12Rank) ? a.h12List + (int64_t)i * (a.h12ChainStride + 8) + 8 : nullptr;
     return w;
 }
 __global__ __launch_bounds__(64) void k_encode_raw_hc(CodecArgs a)
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(64) void k_hc_dict_prime(const uint8_t* dict, int l
 {
     uint8_t* ws = tabs + (size_t)blockIdx.x * kHcWorkBytes;
     HcWork w; w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + kHcHashEntries * 4);
-    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2); w.pre = nullptr;
+    w.opt = (HcOpt*)(ws + kHcHashEntries * 4 + kHcChainEntries * 2); w.pre = nullptr; w.rank = nullptr; w.list = nullptr;
     hc_prime_dict(dict, len, blockIdx.x == 0 ? 2 : 3, w);
 }
 
@@ -1001,9 +1003,15 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             const int64_t stride = (int64_t)round_up((size_t)maxLen + 1, 1024);
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
-            const size_t need = 256 + (size_t)nb * (size_t)stride * 2 + 64;
             size_t budget = (freeB + c->h12Bytes) / 2;
             if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
+            // levels 7..9 (64 candidates and more per search) also get the per-hash lists, if those fit too: their searches
+            // then look at up to 63 candidates per round (hc_find_wider_lists)
+            const size_t chainBytes = round_up((size_t)nb * (size_t)stride * 2, 256);
+            const size_t rankBytes = round_up((size_t)nb * (size_t)stride * 4, 256), listBytes = round_up((size_t)nb * ((size_t)stride + 8) * 4, 256);
+            const size_t offBytes = round_up((size_t)nb * (size_t)kHcHashEntries * 4, 256);
+            const bool lists = a.level >= 7 && a.level <= 9 && 256 + chainBytes + rankBytes + listBytes + offBytes <= budget && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr;
+            const size_t need = 256 + chainBytes + (lists ? rankBytes + listBytes + offBytes : 64);
             if (need <= budget) {
                 if (need > c->h12Bytes) {
                     if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));
@@ -1014,8 +1022,19 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
                     HIPCHK(c, hipMemset(c->d_h12, 0, 256));
                 }
                 a.h12Chain = (uint16_t*)(c->d_h12 + 256); a.h12ChainStride = stride; a.blk0 = 0;
-                a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-                hipLaunchKernelGGL(k_hc_chain, dim3(grid_for(nb, c->cus)), dim3(64), 0, s, a);
+                a.h12Rank = nullptr; a.h12List = nullptr; a.h12Offsets = nullptr;
+                if (lists) {
+                    a.h12Rank = (uint32_t*)(c->d_h12 + 256 + chainBytes);
+                    a.h12List = (uint32_t*)(c->d_h12 + 256 + chainBytes + rankBytes);
+                    a.h12Offsets = (uint32_t*)(c->d_h12 + 256 + chainBytes + rankBytes + listBytes);
+                    a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+                    hipLaunchKernelGGL(k_hc12_hist, dim3(grid_for(nb, c->cus)), dim3(1024), 0, s, a);
+                    a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+                    hipLaunchKernelGGL(k_hc12_chain, dim3(grid_for(nb, c->cus)), dim3(64), 0, s, a);
+                } else {
+                    a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+                    hipLaunchKernelGGL(k_hc_chain, dim3(grid_for(nb, c->cus)), dim3(64), 0, s, a);
+                }
                 HIPCHK(c, hipGetLastError());
             }
         }

@@ -51,7 +51,7 @@ int emu_compress_hc(const uint8_t* src, int n, uint8_t* dst, int cap, int level)
     if (!ws) ws = (uint8_t*)malloc(plz4::kHcWorkBytes);
     plz4::HcWork w;
     w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + plz4::kHcHashEntries * 4);
-    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2); w.pre = nullptr;
+    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2); w.pre = nullptr; w.rank = nullptr; w.list = nullptr;
     return plz4::hc_compress(src, n, dst, cap, level, w);
 }
 
@@ -59,7 +59,7 @@ static plz4::HcWork emu_hc_work(uint8_t* ws)
 {
     plz4::HcWork w;
     w.hash = (uint32_t*)ws; w.chain = (uint16_t*)(ws + plz4::kHcHashEntries * 4);
-    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2); w.pre = nullptr;
+    w.opt = (plz4::HcOpt*)(ws + plz4::kHcHashEntries * 4 + plz4::kHcChainEntries * 2); w.pre = nullptr; w.rank = nullptr; w.list = nullptr;
     return w;
 }
 
@@ -238,4 +238,16 @@ extern "C" int emu_compress_hc_pre(const uint8_t* src, int n, uint8_t* dst, int 
     const int r = hc_compress(padded, n, dst, cap, level, w);
     free(tab); free(chain); free(padded);
     return r;
+}
+
+// ... and with the per-hash lists as well: the hash-chain levels look at up to 63 candidates per round (hc_find_wider_lists)
+extern "C" int emu_compress_hc_lists(const uint8_t* src, int n, uint8_t* dst, int cap, int level)
+{
+    using namespace plz4;
+    H12Emu E(src, n);
+    static thread_local uint8_t* ws = nullptr;
+    if (!ws) ws = (uint8_t*)malloc(kHcWorkBytes);
+    HcWork w = emu_hc_work(ws);
+    w.pre = E.chain; w.rank = E.rank; w.list = E.listBase + 8;
+    return hc_compress(E.padded, n, dst, cap, level, w);
 }

@@ -52,6 +52,12 @@ def main(iters=400, seed=7):
                     if a != b or not np.array_equal(da, db):
                         bad += 1
                         print("MISMATCH pre", it, kind, n, lvl, cap, a, b)
+                if 7 <= lvl <= 9:                        # the 63-candidates-per-round finder on the per-hash lists (hc_find_wider_lists)
+                    b, db = emu.compress_hc_lists(src, cap, lvl)
+                    tot += 1
+                    if a != b or not np.array_equal(da, db):
+                        bad += 1
+                        print("MISMATCH lists", it, kind, n, lvl, cap, a, b)
                 if lvl == 12:                            # the three-phase level-12 path (lz4hc12_device.inl): chain, per-position search, parser
                     for nc, nl in ((0, 1024), (5, 48)):  # nc: positions left to the parser's own search; nl: price-table entries in "LDS"
                         b, db = emu.compress_hc12(src, cap, nc, nl)

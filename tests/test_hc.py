@@ -152,6 +152,30 @@ def test_emu_hc_on_the_chain_built_up_front(ref, orc, emu):
                 assert a == b and np.array_equal(da, db), (name, src.size, lvl, cap, a, b)
 
 
+def test_emu_hc_levels_7_to_9_on_the_lists(ref, orc, emu):
+    """Levels 7..9 as the kernels run them when the per-hash lists fit the workspace: hc_find_wider_lists looks at up to 63
+    candidates of a chain per round, one per lane, and must pick what the one-at-a-time walk picks == LZ4_compress_HC.
+    The P cases are runs of short patterns: they drive the pattern analysis inside the rounds."""
+    cases = [("T", synth.text(70000)), ("Z", np.zeros(9000, np.uint8)), ("M", synth.make("M", 140000, 65536)[60000:])]
+    cases += [(n, c[:6000]) for n, c in corpus.twin_cases()[:3]]
+    cases += [c for c in corpus.small_cases() if c[1].size in (0, 5, 12, 13, 14, 40, 300, 4097)]
+    cases += [("S%d" % s, corpus.structured(30000, s)) for s in range(2)]
+    rng = np.random.default_rng(5)
+    for it in range(6):
+        n = int(rng.integers(1000, 30000)); parts = []; have = 0
+        while have < n:
+            pat = rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8)
+            parts += [np.tile(pat, int(rng.integers(1, 3000))), rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8)]
+            have += parts[-1].size + parts[-2].size
+        cases.append(("P%d" % it, np.concatenate(parts)[:n].copy()))
+    for name, src in cases:
+        for lvl in (7, 8, 9):
+            for cap in (orc.bound(src.size), src.size, max(src.size // 3, 1)):
+                a, da = ref.compress_hc(src, cap, lvl)
+                b, db = emu.compress_hc_lists(src, cap, lvl)
+                assert a == b and np.array_equal(da, db), (name, src.size, lvl, cap, a, b)
+
+
 # ---- level 12 in its three device phases (plz4_amd/csrc/lz4hc12_device.inl): chains + per-hash lists, F(p) per position, parser
 def test_emu_hc12_vs_reference(ref, orc, emu):
     """The three phases back to back on the CPU == LZ4_compress_HC(level 12), incl. the parser's own search for positions the
