@@ -289,7 +289,7 @@ template <bool kD>
 DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches,
                           bool patternAnalysis, bool chainSwap)
 {
-    if (!kD && !chainSwap && s.w.list && nbSearches >= 64)      // levels 7..9 on an independent block: 63 candidates per round
+    if (!kD && !chainSwap && s.w.list && nbSearches >= 16)      // levels 5..9 on an independent block: 63 candidates per round
         return hc_find_wider_lists(s, pos, lowLimit, highLimit, longest, nbSearches, patternAnalysis);
     const uint8_t* const src = s.src;
     const uint8_t* const ip = src + pos;

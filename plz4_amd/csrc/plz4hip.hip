@@ -1005,19 +1005,32 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
             size_t budget = (freeB + c->h12Bytes) / 2;
             if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
-            // levels 7..9 (64 candidates and more per search) also get the per-hash lists, if those fit too: their searches
+            // the lists are worth more memory than that: these kernels live on the number of blocks in flight (7 waves per SIMD
+            // fit), and 4096 blocks of 4 MiB with their lists (40 MiB each) are 160 GiB -- up to three quarters of what is free;
+            // plz4hip_ctx_trim gives it back
+            size_t budgetLists = (freeB + c->h12Bytes) / 4 * 3;
+            if (const char* v = getenv("PLZ4HIP_HC_BUDGET_GIB")) { const long g = atol(v); if (g >= 1) budget = budgetLists = (size_t)g << 30; }
+            // levels 5..9 (16 candidates and more per search) also get the per-hash lists, if those fit too: their searches
             // then look at up to 63 candidates per round (hc_find_wider_lists)
             const size_t chainBytes = round_up((size_t)nb * (size_t)stride * 2, 256);
             const size_t rankBytes = round_up((size_t)nb * (size_t)stride * 4, 256), listBytes = round_up((size_t)nb * ((size_t)stride + 8) * 4, 256);
             const size_t offBytes = round_up((size_t)nb * (size_t)kHcHashEntries * 4, 256);
-            const bool lists = a.level >= 7 && a.level <= 9 && 256 + chainBytes + rankBytes + listBytes + offBytes <= budget && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr;
-            const size_t need = 256 + chainBytes + (lists ? rankBytes + listBytes + offBytes : 64);
-            if (need <= budget) {
+            const size_t needLists = 256 + chainBytes + rankBytes + listBytes + offBytes;      // (what the ctx already holds is not up for discussion)
+            bool lists = a.level >= 5 && a.level <= 9 && (needLists <= budgetLists || needLists <= c->h12Bytes) && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr;
+            size_t need = 256 + chainBytes + (lists ? rankBytes + listBytes + offBytes : 64);
+            if (getenv("PLZ4HIP_VERBOSE"))
+                fprintf(stderr, "plz4hip: HC level %d, %d blocks: free %zu MiB, held %zu MiB, lists %d (need %zu MiB of %zu)\n", a.level, nb,
+                        freeB >> 20, c->h12Bytes >> 20, (int)lists, need >> 20, (lists ? budgetLists : budget) >> 20);
+            if (need <= (lists ? budgetLists : budget) || need <= c->h12Bytes) {
                 if (need > c->h12Bytes) {
                     if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));
                     if (c->d_h12) hipFree(c->d_h12);
                     c->d_h12 = nullptr; c->h12Bytes = 0;
-                    if (hipMalloc((void**)&c->d_h12, need) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "HC chain workspace");
+                    if (lists && hipMalloc((void**)&c->d_h12, need) != hipSuccess) {       // the large request refused: the chain alone
+                        (void)hipGetLastError();
+                        c->d_h12 = nullptr; lists = false; need = 256 + chainBytes + 64;
+                    }
+                    if (!c->d_h12 && hipMalloc((void**)&c->d_h12, need) != hipSuccess) { c->d_h12 = nullptr; return fail(c, PLZ4HIP_E_NOMEM, "HC chain workspace"); }
                     c->h12Bytes = need;
                     HIPCHK(c, hipMemset(c->d_h12, 0, 256));
                 }
