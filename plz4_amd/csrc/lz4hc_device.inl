@@ -153,7 +153,7 @@ DEV bool hc_protect(uint32_t prefixIdx, uint32_t mi) { return (uint32_t)((prefix
 // chain links are evaluated together, and the first lane where something happens (the tests pass: the match is measured; the
 // link is 1: pattern analysis, level 9) is handled exactly as the reference handles that candidate; the lanes below it were
 // candidates that change nothing.  One dependent memory round trip per ROUND instead of one per candidate.
-DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches, bool patternAnalysis)
+DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches, bool patternAnalysis, bool chainSwap)
 {
     const uint8_t* const src = s.src;
     const uint8_t* const ip = src + pos;
@@ -166,6 +166,7 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
     const uint32_t pattern = UNI(ld32u(ip));
     int offset = 0, sBack = 0, attempts = nbSearches, repeat = 0;
     size_t srcPatternLength = 0;
+    uint32_t chainPos = 0;       // chain swap (:964-987): the walk follows the chain of position candidate + chainPos
     HcMatch out;
     const uint32_t head = UNI((uint32_t)s.w.pre[pos]);
     if (head) {
@@ -186,7 +187,8 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
             const uint64_t ends = BALLOT(fl[I_] != 0);                          // the chain's first position sits in this lane
             const int lastOfChain = ends ? ctz64(ends) : 64;
             const int attL = attempts;
-            const uint64_t dead = BALLOT(LANE > lastOfChain || q[I_] + kHcBase < lowest || LANE >= attL || LANE >= 63);
+            const int cp = (int)chainPos;
+            const uint64_t dead = BALLOT(LANE > lastOfChain || (int)q[I_] - cp + (int)kHcBase < (int)lowest || LANE >= attL || LANE >= 63);
             const int nvalid = dead ? ctz64(dead) : 63;                          // lane 0 is the current candidate: valid by the loop test
             LV(uint32_t, dn);
             LANES({
@@ -200,9 +202,9 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                 LANES({
                     pass[I_] = 0; pat[I_] = 0;
                     if (LANE < nv) {
-                        const uint8_t* mp = src + q[I_];
+                        const uint8_t* mp = src + q[I_] - cp;
                         pass[I_] = (ld16u(mp - lookBack + L - 1) == ip16) && (ld32u(mp) == pattern);
-                        pat[I_] = patternAnalysis && dn[I_] == 1u;
+                        pat[I_] = patternAnalysis && dn[I_] == 1u && cp == 0;
                     }
                 })
             }
@@ -217,12 +219,12 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                 const int used = kSat < nvalid ? kSat + 1 : nvalid;
                 attempts -= used;
                 if (kSat < nvalid || used > lastOfChain) break;                  // saturated link / the chain's first position consumed
-                mi = RL(q, used - 1) - RL(dn, used - 1) + kHcBase;                // the candidate below the last one looked at
+                mi = RL(q, used - 1) - RL(dn, used - 1) - chainPos + kHcBase;                // the candidate below the last one looked at
                 cursor -= used;
                 continue;
             }
             attempts -= k + 1;
-            mi = RL(q, k) + kHcBase;
+            mi = RL(q, k) - chainPos + kHcBase;
             const uint32_t dnk = RL(dn, k);
             const uint8_t* const mp = src + (mi - kHcBase);
             if (RL(pass, k)) {                                                    // :933-939
@@ -230,6 +232,24 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                 int mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
                 mlen -= back;
                 if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
+                if (chainSwap && mlen == longest && mi + (uint32_t)longest <= ipIndex) {               // :964-987, as in hc_find_wider
+                    uint32_t distNext = 1;
+                    const int end = longest - kMinMatch + 1;
+                    int step = 1, accel = 1 << 4;
+                    LV(uint32_t, links);
+                    { const uint32_t mi0 = mi; LANES({ links[I_] = (LANE < end) ? hc_link(s, mi0 + (uint32_t)LANE) : 0u; }) }
+                    for (int p2 = 0; p2 < end; p2 += step) {
+                        const uint32_t cd = p2 < 64 ? RL(links, p2) : hc_link(s, mi + (uint32_t)p2);
+                        step = (accel++ >> 4);
+                        if (cd > distNext) { distNext = cd; chainPos = (uint32_t)p2; accel = 1 << 4; }
+                    }
+                    if (distNext > 1) {
+                        if (distNext > mi || distNext >= 65535u) break;          // (a saturated link leads below the window: the walk ends)
+                        cursor = (int)UNI(s.w.rank[mi - kHcBase + chainPos]) - 1;
+                        mi -= distNext;
+                        continue;
+                    }
+                }
             }
             bool jumped = false;
             if (RL(pat, k)) {                                                     // :989-1062 (chainPos is 0 without chain swap)
@@ -289,8 +309,8 @@ template <bool kD>
 DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches,
                           bool patternAnalysis, bool chainSwap)
 {
-    if (!kD && !chainSwap && s.w.list && nbSearches >= 16)      // levels 5..9 on an independent block: 63 candidates per round
-        return hc_find_wider_lists(s, pos, lowLimit, highLimit, longest, nbSearches, patternAnalysis);
+    if (!kD && s.w.list && nbSearches >= 16)                    // levels 5..11 on an independent block: 63 candidates per round
+        return hc_find_wider_lists(s, pos, lowLimit, highLimit, longest, nbSearches, patternAnalysis, chainSwap);
     const uint8_t* const src = s.src;
     const uint8_t* const ip = src + pos;
     const uint8_t* const iLow = src + lowLimit;

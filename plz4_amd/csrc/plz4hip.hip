@@ -1016,7 +1016,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             const size_t rankBytes = round_up((size_t)nb * (size_t)stride * 4, 256), listBytes = round_up((size_t)nb * ((size_t)stride + 8) * 4, 256);
             const size_t offBytes = round_up((size_t)nb * (size_t)kHcHashEntries * 4, 256);
             const size_t needLists = 256 + chainBytes + rankBytes + listBytes + offBytes;      // (what the ctx already holds is not up for discussion)
-            bool lists = a.level >= 5 && a.level <= 9 && (needLists <= budgetLists || needLists <= c->h12Bytes) && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr;
+            bool lists = a.level >= 5 && a.level <= 11 && (needLists <= budgetLists || needLists <= c->h12Bytes) && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr;
             size_t need = 256 + chainBytes + (lists ? rankBytes + listBytes + offBytes : 64);
             if (getenv("PLZ4HIP_VERBOSE"))
                 fprintf(stderr, "plz4hip: HC level %d, %d blocks: free %zu MiB, held %zu MiB, lists %d (need %zu MiB of %zu)\n", a.level, nb,
