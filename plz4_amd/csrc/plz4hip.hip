@@ -1010,13 +1010,13 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             // plz4hip_ctx_trim gives it back
             size_t budgetLists = (freeB + c->h12Bytes) / 4 * 3;
             if (const char* v = getenv("PLZ4HIP_HC_BUDGET_GIB")) { const long g = atol(v); if (g >= 1) budget = budgetLists = (size_t)g << 30; }
-            // levels 5..9 (16 candidates and more per search) also get the per-hash lists, if those fit too: their searches
+            // levels 5..12 (16 candidates and more per search) also get the per-hash lists, if those fit too: their searches
             // then look at up to 63 candidates per round (hc_find_wider_lists)
             const size_t chainBytes = round_up((size_t)nb * (size_t)stride * 2, 256);
             const size_t rankBytes = round_up((size_t)nb * (size_t)stride * 4, 256), listBytes = round_up((size_t)nb * ((size_t)stride + 8) * 4, 256);
             const size_t offBytes = round_up((size_t)nb * (size_t)kHcHashEntries * 4, 256);
             const size_t needLists = 256 + chainBytes + rankBytes + listBytes + offBytes;      // (what the ctx already holds is not up for discussion)
-            bool lists = a.level >= 5 && a.level <= 11 && (needLists <= budgetLists || needLists <= c->h12Bytes) && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr;
+            bool lists = a.level >= 5 && a.level <= 12 && (needLists <= budgetLists || needLists <= c->h12Bytes) && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr;
             size_t need = 256 + chainBytes + (lists ? rankBytes + listBytes + offBytes : 64);
             if (getenv("PLZ4HIP_VERBOSE"))
                 fprintf(stderr, "plz4hip: HC level %d, %d blocks: free %zu MiB, held %zu MiB, lists %d (need %zu MiB of %zu)\n", a.level, nb,
