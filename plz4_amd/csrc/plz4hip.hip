@@ -312,7 +312,8 @@ __device__ __forceinline__ HcDict hc_dict_of(const CodecArgs& a, int i, int n, c
     }
     return d;
 }
-// independent block i without dictionary: its chain was built up front (k_hc_chain) when the call's launcher found room for it
+// independent block without dictionary, the i-th of its group: its chain (and lists) were built up front when the call's
+// launcher found room for them
 __device__ __forceinline__ HcWork hc_with_pre(HcWork w, const CodecArgs& a, int i)
 {
     w.pre = a.h12Chain ? a.h12Chain + (int64_t)i * a.h12ChainStride : nullptr;
@@ -324,13 +325,14 @@ __global__ __launch_bounds__(64) void k_encode_raw_hc(CodecArgs a)
 {
     const HcWork w = hc_work_of(a);
     const bool dictMode = a.hcEx != 0;
-    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+    for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
+        const int i = a.blk0 + g;                                        // (the chain / lists workspace is the group's: index g)
         const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
         const int n = block_len(a, i);
         const uint8_t* s = a.src + (int64_t)i * a.srcStride;
         int r;
         if (dictMode) r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, w, hc_dict_of(a, i, n, s, true));
-        else          r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, hc_with_pre(w, a, i));
+        else          r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, hc_with_pre(w, a, g));
         if ((threadIdx.x & 63u) == 0) a.result[i] = r;
     }
 }
@@ -338,13 +340,14 @@ __global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
 {
     const HcWork w = hc_work_of(a);
     const bool exMode = a.hcEx != 0;
-    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+    for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
+        const int      i   = a.blk0 + g;
         const int      n   = block_len(a, i);
         const uint8_t* s   = a.src + (int64_t)i * a.srcStride;
         uint8_t*       rec = a.dst + (int64_t)i * a.dstStride;
         int c;                                                           // capacity == bsz (blk.go:73); indie.go:80-88
         if (exMode) c = hc_compress(s, n, rec + 4, a.bsz, a.level, w, hc_dict_of(a, i, n, s, false));
-        else        c = hc_compress(s, n, rec + 4, a.bsz, a.level, hc_with_pre(w, a, i));
+        else        c = hc_compress(s, n, rec + 4, a.bsz, a.level, hc_with_pre(w, a, g));
         uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
         WAVE_FENCE();
         if (c == 0) { wave_copy(rec + 4, s, n); c = n; word = 0x80000000u | ((uint32_t)n & 0x7FFFFFFFu); }
@@ -418,11 +421,12 @@ __global__ __launch_bounds__(64) void k_hc12_chain(CodecArgs a)
 __global__ __launch_bounds__(64) void k_hc_chain(CodecArgs a)
 {
     __shared__ uint32_t tab[kHcHashEntries];
-    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+    for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
+        const int i = a.blk0 + g;
         const int n = block_len(a, i);
         int nPad = (n + 1 + 1023) & ~1023;
         if (nPad > a.h12ChainStride) nPad = (int)a.h12ChainStride;
-        hc12_build_chain(a.src + (int64_t)i * a.srcStride, n, a.h12Chain + (int64_t)i * a.h12ChainStride, nPad, tab);
+        hc12_build_chain(a.src + (int64_t)i * a.srcStride, n, a.h12Chain + (int64_t)g * a.h12ChainStride, nPad, tab);
     }
 }
 
@@ -997,64 +1001,95 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         if (int rc = ensure_hc(c)) return rc;
         a.hcWork = c->d_hc; a.nBlocks = nb;
         a.h12Chain = nullptr;
+        a.blk0 = 0;
+        int per = nb;                     // blocks per launch
+        bool lists = false;
+        size_t chainBytes = 0, rankBytes = 0, listBytes = 0;
         if (a.level >= 3 && !a.hcEx && maxLen >= 4096 && getenv("PLZ4HIP_HC_PRE_OFF") == nullptr) {
-            // levels 3..11, independent blocks: the chain of every block of the call built up front (2 B per position), if it
-            // fits the budget of plan_h12; the parsers then run without their 4 M dependent table updates per 4 MiB block
+            // levels 3..12, independent blocks: the chain of every block built up front (2 B per position): the parsers then run
+            // without their 4 M dependent table updates per 4 MiB block.  Levels 5..12 (16 candidates and more per search)
+            // also get the per-hash lists (another 8 B per position): their searches then look at up to 63 candidates per
+            // round (hc_find_wider_lists).  A call whose blocks do not fit the memory set aside runs in groups of equal size.
             const int64_t stride = (int64_t)round_up((size_t)maxLen + 1, 1024);
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
-            size_t budget = (freeB + c->h12Bytes) / 2;
+            size_t budget = (freeB + c->h12Bytes) / 2;                   // the chain alone: as plan_h12
             if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
             // the lists are worth more memory than that: these kernels live on the number of blocks in flight (7 waves per SIMD
             // fit), and 4096 blocks of 4 MiB with their lists (40 MiB each) are 160 GiB -- up to three quarters of what is free;
-            // plz4hip_ctx_trim gives it back
+            // plz4hip_ctx_trim gives it back.  What the ctx already holds is used in any case.
             size_t budgetLists = (freeB + c->h12Bytes) / 4 * 3;
             if (const char* v = getenv("PLZ4HIP_HC_BUDGET_GIB")) { const long g = atol(v); if (g >= 1) budget = budgetLists = (size_t)g << 30; }
-            // levels 5..12 (16 candidates and more per search) also get the per-hash lists, if those fit too: their searches
-            // then look at up to 63 candidates per round (hc_find_wider_lists)
-            const size_t chainBytes = round_up((size_t)nb * (size_t)stride * 2, 256);
-            const size_t rankBytes = round_up((size_t)nb * (size_t)stride * 4, 256), listBytes = round_up((size_t)nb * ((size_t)stride + 8) * 4, 256);
-            const size_t offBytes = round_up((size_t)nb * (size_t)kHcHashEntries * 4, 256);
-            const size_t needLists = 256 + chainBytes + rankBytes + listBytes + offBytes;      // (what the ctx already holds is not up for discussion)
-            bool lists = a.level >= 5 && a.level <= 12 && (needLists <= budgetLists || needLists <= c->h12Bytes) && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr;
-            size_t need = 256 + chainBytes + (lists ? rankBytes + listBytes + offBytes : 64);
+            if (budget < c->h12Bytes) budget = c->h12Bytes;
+            if (budgetLists < c->h12Bytes) budgetLists = c->h12Bytes;
+            const size_t slack = 256 + 4 * 256;
+            const size_t chainPer = (size_t)stride * 2;
+            const size_t listsPer = chainPer + (size_t)stride * 4 + ((size_t)stride + 8) * 4 + (size_t)kHcHashEntries * 4;
+            const auto groups_of = [&](size_t room, size_t perBlock) {          // blocks per launch, groups of equal size
+                int64_t g = room > slack ? (int64_t)((room - slack) / perBlock) : 0;
+                if (const char* v = getenv("PLZ4HIP_HC_GROUP")) { const int gv = atoi(v); if (gv >= 1 && gv < g) g = gv; }
+                if (g < 1) return 0;
+                if (g > nb) g = nb;
+                const int n = (int)((nb + g - 1) / g);
+                return (nb + n - 1) / n;
+            };
+            const int perLists = (a.level >= 5 && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr) ? groups_of(budgetLists, listsPer) : 0;
+            const int perChain = groups_of(budget, chainPer);
+            // a group has to keep the chip busy: below 2048 blocks in flight the lists lose to the chain alone over more blocks
+            // at levels 5..9; the optimal parser's levels gain an order of magnitude and take them in any case
+            lists = perLists >= 1 && (perLists == nb || perLists >= (a.level >= 10 ? 256 : 2048) || perChain < 1);
+            if (lists && perLists > c->h12Bytes / listsPer) {             // try the large request first: refused -> the chain alone
+                if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));
+                if (c->d_h12) hipFree(c->d_h12);
+                c->d_h12 = nullptr; c->h12Bytes = 0;
+                const size_t need = slack + (size_t)perLists * listsPer;
+                if (hipMalloc((void**)&c->d_h12, need) != hipSuccess) { (void)hipGetLastError(); c->d_h12 = nullptr; lists = false; }
+                else { c->h12Bytes = need; HIPCHK(c, hipMemset(c->d_h12, 0, 256)); }
+            }
+            const int perPre = lists ? perLists : perChain;
             if (getenv("PLZ4HIP_VERBOSE"))
-                fprintf(stderr, "plz4hip: HC level %d, %d blocks: free %zu MiB, held %zu MiB, lists %d (need %zu MiB of %zu)\n", a.level, nb,
-                        freeB >> 20, c->h12Bytes >> 20, (int)lists, need >> 20, (lists ? budgetLists : budget) >> 20);
-            if (need <= (lists ? budgetLists : budget) || need <= c->h12Bytes) {
+                fprintf(stderr, "plz4hip: HC level %d, %d blocks: free %zu MiB, held %zu MiB, lists %d, %d blocks per group\n", a.level, nb,
+                        freeB >> 20, c->h12Bytes >> 20, (int)lists, perPre);
+            if (perPre >= 1) {
+                per = perPre;
+                const size_t need = slack + (size_t)per * (lists ? listsPer : chainPer);
                 if (need > c->h12Bytes) {
                     if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));
                     if (c->d_h12) hipFree(c->d_h12);
                     c->d_h12 = nullptr; c->h12Bytes = 0;
-                    if (lists && hipMalloc((void**)&c->d_h12, need) != hipSuccess) {       // the large request refused: the chain alone
-                        (void)hipGetLastError();
-                        c->d_h12 = nullptr; lists = false; need = 256 + chainBytes + 64;
-                    }
-                    if (!c->d_h12 && hipMalloc((void**)&c->d_h12, need) != hipSuccess) { c->d_h12 = nullptr; return fail(c, PLZ4HIP_E_NOMEM, "HC chain workspace"); }
+                    if (hipMalloc((void**)&c->d_h12, need) != hipSuccess) { c->d_h12 = nullptr; return fail(c, PLZ4HIP_E_NOMEM, "HC chain workspace"); }
                     c->h12Bytes = need;
                     HIPCHK(c, hipMemset(c->d_h12, 0, 256));
                 }
-                a.h12Chain = (uint16_t*)(c->d_h12 + 256); a.h12ChainStride = stride; a.blk0 = 0;
+                chainBytes = round_up((size_t)per * chainPer, 256);
+                rankBytes = round_up((size_t)per * (size_t)stride * 4, 256);
+                listBytes = round_up((size_t)per * ((size_t)stride + 8) * 4, 256);
+                a.h12Chain = (uint16_t*)(c->d_h12 + 256); a.h12ChainStride = stride;
                 a.h12Rank = nullptr; a.h12List = nullptr; a.h12Offsets = nullptr;
                 if (lists) {
                     a.h12Rank = (uint32_t*)(c->d_h12 + 256 + chainBytes);
                     a.h12List = (uint32_t*)(c->d_h12 + 256 + chainBytes + rankBytes);
                     a.h12Offsets = (uint32_t*)(c->d_h12 + 256 + chainBytes + rankBytes + listBytes);
-                    a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-                    hipLaunchKernelGGL(k_hc12_hist, dim3(grid_for(nb, c->cus)), dim3(1024), 0, s, a);
-                    a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-                    hipLaunchKernelGGL(k_hc12_chain, dim3(grid_for(nb, c->cus)), dim3(64), 0, s, a);
-                } else {
-                    a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-                    hipLaunchKernelGGL(k_hc_chain, dim3(grid_for(nb, c->cus)), dim3(64), 0, s, a);
                 }
-                HIPCHK(c, hipGetLastError());
             }
         }
-        a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-        if (rawMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
-        else         hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, a);
-        HIPCHK(c, hipGetLastError());
+        for (int g0 = 0; g0 < nb; g0 += per) {
+            const int ng = nb - g0 < per ? nb - g0 : per;
+            a.blk0 = g0; a.nBlocks = ng;
+            if (a.h12Chain && lists) {
+                a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+                hipLaunchKernelGGL(k_hc12_hist, dim3(grid_for(ng, c->cus)), dim3(1024), 0, s, a);
+                a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+                hipLaunchKernelGGL(k_hc12_chain, dim3(grid_for(ng, c->cus)), dim3(64), 0, s, a);
+            } else if (a.h12Chain) {
+                a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+                hipLaunchKernelGGL(k_hc_chain, dim3(grid_for(ng, c->cus)), dim3(64), 0, s, a);
+            }
+            a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+            if (rawMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(ng, c->hcWaves)), dim3(64), 0, s, a);
+            else         hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(ng, c->hcWaves)), dim3(64), 0, s, a);
+            HIPCHK(c, hipGetLastError());
+        }
     }
     return hc_leave(c, s);
 }

@@ -1,6 +1,6 @@
 # Round-2 profiles (run on the GPU box through gpurun; outputs under gpurun_out/prof_<tag>/, summarised into profiles/ by
 # scripts/summarize_profile.py).  The program follows `--` directly (no env/bash hop); counters in passes of their own.
-#   bash scripts/gpu_profile_r02.sh l1|c4|c5
+#   bash scripts/gpu_profile_r02.sh l1|c4|c5|hc
 set -x
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
@@ -19,5 +19,7 @@ case $W in
 l1) prof r02 python3 $R/bench.py --blocks 6144 --steps 2 --warmup 1 --no-cpu-baseline ;;
 c4) prof r02_config4_level12 python3 $R/bench.py --level 12 --blocks 1024 --steps 1 --warmup 1 --no-cpu-baseline
     prof r02_level3 python3 $R/bench.py --level 3 --blocks 1024 --steps 1 --warmup 1 --no-cpu-baseline ;;
+hc) prof r02_level9_lists python3 $R/bench.py --level 9 --blocks 1024 --steps 1 --warmup 0 --no-cpu-baseline
+    prof r02_level11_lists python3 $R/bench.py --level 11 --blocks 1024 --steps 1 --warmup 0 --no-cpu-baseline ;;
 c5) prof r02_config5 python3 $R/scripts/config5_rate.py 512 ;;
 esac

@@ -285,6 +285,30 @@ def test_gpu_hc12_groups_and_streams(ref, orc, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_gpu_hc_chain_and_lists_in_groups(ref, orc, monkeypatch):
+    """Levels 3..11 on the chain / lists built up front, the call cut into groups of 3 blocks (what a call beyond the memory set
+    aside does): records and raw blocks as the reference's, whichever group a block falls into."""
+    from plz4_amd._native import Engine
+    bsz = 256 << 10
+    data = synth.make("M", 10 * bsz + 4321, bsz)
+    srcs = [data[o:o + bsz] for o in range(0, data.size, bsz)]
+    monkeypatch.setenv("PLZ4HIP_HC_GROUP", "3")
+    eng = Engine(0)
+    for lvl in (3, 6, 9, 10, 11):
+        recs = eng.encode_records(srcs, bsz, True, level=lvl)
+        res, outs = eng.compress_batch(srcs, [orc.bound(s.size) for s in srcs], level=lvl)
+        for i, (s, rec) in enumerate(zip(srcs, recs)):
+            n, c = ref.compress_hc(s, bsz, lvl)
+            if n:
+                assert not (rec[3] & 0x80) and np.array_equal(rec[4:-4], c[:n]), (lvl, i)
+            else:
+                assert rec[3] & 0x80 and np.array_equal(rec[4:-4], s), (lvl, i)
+            n2, c2 = ref.compress_hc(s, orc.bound(s.size), lvl)
+            assert int(res[i]) == n2 and np.array_equal(outs[i], c2), (lvl, i)
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_gpu_hc12_block_sizes_beyond_the_frame_path(ref, orc):
     """The raw block API takes blocks of any size: 5 MiB runs the three-phase kernels (positions beyond 22 bits), 9 MiB falls back
     to the one-thread-per-block kernel (the three-phase writer packs positions into 23 bits); a batch of ragged sizes too."""
