@@ -175,7 +175,7 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
         while (mi >= lowest && attempts > 0) {
             // lane k: the candidate k places below the current one in the chain (list[cursor - k]); 64 entries are fetched so
             // that every one of the 63 candidates knows its link (the distance to the next candidate)
-            LV(uint32_t, q); LV(int, fl); LV(int, pass); LV(int, pat);
+            LV(uint32_t, q); LV(int, fl); LV(int, pat);
             {
                 const int curL = cursor;
                 LANES({ const uint32_t e = (curL - LANE >= -8) ? s.w.list[curL - LANE] : 0x80000000u; q[I_] = e & 0x7FFFFFFFu; fl[I_] = (int)(e >> 31); })
@@ -196,106 +196,130 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                 const uint32_t d = hasNext ? q[I_] - qn[I_] : 65535u;
                 dn[I_] = d < 65535u ? d : 65535u;
             })
-            const uint32_t ip16 = UNI((uint32_t)ld16u(iLow + longest - 1));
+            // the candidates' 4-byte prefixes, once per round; the 2 bytes at `longest - 1` (:921) again whenever `longest` grows
+            // (both requested together the first time: one memory round trip)
+            LV(int, pfx); LV(int, pass);
             {
+                const uint32_t ip16 = UNI((uint32_t)ld16u(iLow + longest - 1));
                 const int nv = nvalid, L = longest;
                 LANES({
-                    pass[I_] = 0; pat[I_] = 0;
+                    pfx[I_] = 0; pass[I_] = 0; pat[I_] = 0;
                     if (LANE < nv) {
                         const uint8_t* mp = src + q[I_] - cp;
-                        pass[I_] = (ld16u(mp - lookBack + L - 1) == ip16) && (ld32u(mp) == pattern);
+                        const uint32_t m16 = ld16u(mp - lookBack + L - 1);
+                        pfx[I_] = ld32u(mp) == pattern;
+                        pass[I_] = pfx[I_] && m16 == ip16;
                         pat[I_] = patternAnalysis && dn[I_] == 1u && cp == 0;
                     }
                 })
             }
             // the walk also ends inside the round where a link is saturated: the candidate behind it is never looked at
             const uint64_t sat = BALLOT(LANE < nvalid && dn[I_] >= 65535u);
-            const uint64_t ev = BALLOT(LANE < nvalid && (pass[I_] || pat[I_]));
             const int kSat = sat ? ctz64(sat) : 64;
-            int k = ev ? ctz64(ev) : 64;
-            if (k > kSat) k = 64;                                                 // nothing happens before the walk ends
-            if (k == 64) {
-                // every candidate of the round changes nothing
-                const int used = kSat < nvalid ? kSat + 1 : nvalid;
-                attempts -= used;
-                if (kSat < nvalid || used > lastOfChain) break;                  // saturated link / the chain's first position consumed
-                mi = RL(q, used - 1) - RL(dn, used - 1) - chainPos + kHcBase;                // the candidate below the last one looked at
-                cursor -= used;
-                continue;
-            }
-            attempts -= k + 1;
-            mi = RL(q, k) - chainPos + kHcBase;
-            const uint32_t dnk = RL(dn, k);
-            const uint8_t* const mp = src + (mi - kHcBase);
-            if (RL(pass, k)) {                                                    // :933-939
-                const int back = lookBack ? hc_count_back(ip, mp, iLow, src) : 0;
-                int mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
-                mlen -= back;
-                if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
-                if (chainSwap && mlen == longest && mi + (uint32_t)longest <= ipIndex) {               // :964-987, as in hc_find_wider
-                    uint32_t distNext = 1;
-                    const int end = longest - kMinMatch + 1;
-                    int step = 1, accel = 1 << 4;
-                    LV(uint32_t, links);
-                    { const uint32_t mi0 = mi; LANES({ links[I_] = (LANE < end) ? hc_link(s, mi0 + (uint32_t)LANE) : 0u; }) }
-                    for (int p2 = 0; p2 < end; p2 += step) {
-                        const uint32_t cd = p2 < 64 ? RL(links, p2) : hc_link(s, mi + (uint32_t)p2);
-                        step = (accel++ >> 4);
-                        if (cd > distNext) { distNext = cd; chainPos = (uint32_t)p2; accel = 1 << 4; }
-                    }
-                    if (distNext > 1) {
-                        if (distNext > mi || distNext >= 65535u) break;          // (a saturated link leads below the window: the walk ends)
-                        cursor = (int)UNI(s.w.rank[mi - kHcBase + chainPos]) - 1;
-                        mi -= distNext;
-                        continue;
-                    }
+            const int endLane = kSat < nvalid ? kSat + 1 : nvalid;                // lanes [0, endLane) are what the walk can reach
+            int start = 0;                                                        // lanes below it are done
+            int passFor = longest;                                                // the `longest` that pass[] was made for
+            bool walkEnds = false, nextRound = false;
+            while (!walkEnds && !nextRound) {
+                if (passFor != longest) {
+                    const uint32_t ip16 = UNI((uint32_t)ld16u(iLow + longest - 1));
+                    const int L = longest, st = start, en = endLane;
+                    LANES({
+                        pass[I_] = 0;
+                        if (LANE >= st && LANE < en && pfx[I_]) pass[I_] = ld16u(src + q[I_] - cp - lookBack + L - 1) == ip16;
+                    })
+                    passFor = longest;
                 }
-            }
-            bool jumped = false;
-            if (RL(pat, k)) {                                                     // :989-1062 (chainPos is 0 without chain swap)
-                const uint32_t mci = mi - 1;
-                if (repeat == 0) {
-                    if (((pattern & 0xFFFFu) == (pattern >> 16)) & ((pattern & 0xFFu) == (pattern >> 24))) {
-                        repeat = 2;
-                        srcPatternLength = hc_count_pattern(ip + 4, iHigh, pattern) + 4;
-                    } else repeat = 1;
+                const int st0 = start;
+                const uint64_t ev = BALLOT(LANE >= st0 && LANE < endLane && (pass[I_] || pat[I_]));
+                const int k = ev ? ctz64(ev) : 64;
+                if (k == 64) {
+                    // every remaining candidate of the round changes nothing
+                    attempts -= endLane - start;
+                    if (kSat < nvalid || endLane > lastOfChain) { walkEnds = true; break; }   // saturated link / the chain's first position consumed
+                    mi = RL(q, endLane - 1) - RL(dn, endLane - 1) - chainPos + kHcBase;       // the candidate below the last one looked at
+                    cursor -= endLane;
+                    nextRound = true;
+                    break;
                 }
-                if (repeat == 2 && mci >= lowest) {
-                    const uint8_t* const mq = src + (mci - kHcBase);
-                    if (UNI(ld32u(mq)) == pattern) {
-                        const size_t fwd = hc_count_pattern(mq + 4, iHigh, pattern) + 4;
-                        size_t back = hc_rcount_pattern(mq, src, pattern);
-                        {   const uint32_t far = mci - (uint32_t)back;
-                            back = mci - (far > lowest ? far : lowest); }
-                        const size_t seg = back + fwd;
-                        bool stop = false;
-                        if (seg >= srcPatternLength && fwd <= srcPatternLength) {
-                            mi = mci + (uint32_t)fwd - (uint32_t)srcPatternLength;     // :1027-1036: looked at next
-                            cursor = (int)UNI(s.w.rank[mi - kHcBase]);
-                        } else {
-                            mi = mci - (uint32_t)back;                                 // :1038-1058
-                            if (lookBack == 0) {
-                                const size_t maxML = seg < srcPatternLength ? seg : srcPatternLength;
-                                if ((size_t)longest < maxML) {
-                                    if (ipIndex - mi > 65535u) stop = true;
-                                    else { longest = (int)maxML; offset = (int)(ipIndex - mi); }
-                                }
-                                if (!stop) {
-                                    const uint32_t dp = hc_link(s, mi);
-                                    if (dp > mi) stop = true;
-                                    else { const uint32_t at = mi - kHcBase; mi -= dp; cursor = (int)UNI(s.w.rank[at]) - 1; if (dp >= 65535u) stop = true; }
-                                }
-                            } else cursor = (int)UNI(s.w.rank[mi - kHcBase]);
+                attempts -= k - start + 1;
+                mi = RL(q, k) - chainPos + kHcBase;
+                const uint32_t dnk = RL(dn, k);
+                const uint8_t* const mp = src + (mi - kHcBase);
+                if (RL(pass, k)) {                                                    // :933-939
+                    const int back = lookBack ? hc_count_back(ip, mp, iLow, src) : 0;
+                    int mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
+                    mlen -= back;
+                    if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
+                    if (chainSwap && mlen == longest && mi + (uint32_t)longest <= ipIndex) {               // :964-987, as in hc_find_wider
+                        uint32_t distNext = 1;
+                        const int end = longest - kMinMatch + 1;
+                        int step = 1, accel = 1 << 4;
+                        LV(uint32_t, links);
+                        { const uint32_t mi0 = mi; LANES({ links[I_] = (LANE < end) ? hc_link(s, mi0 + (uint32_t)LANE) : 0u; }) }
+                        for (int p2 = 0; p2 < end; p2 += step) {
+                            const uint32_t cd = p2 < 64 ? RL(links, p2) : hc_link(s, mi + (uint32_t)p2);
+                            step = (accel++ >> 4);
+                            if (cd > distNext) { distNext = cd; chainPos = (uint32_t)p2; accel = 1 << 4; }
                         }
-                        if (stop) break;
-                        jumped = true;
+                        if (distNext > 1) {
+                            if (distNext > mi || distNext >= 65535u) { walkEnds = true; break; }   // (a saturated link leads below the window: the walk ends)
+                            cursor = (int)UNI(s.w.rank[mi - kHcBase + chainPos]) - 1;
+                            mi -= distNext;
+                            nextRound = true;
+                            break;
+                        }
                     }
                 }
+                if (RL(pat, k)) {                                                     // :989-1062 (chainPos is 0 here)
+                    const uint32_t mci = mi - 1;
+                    if (repeat == 0) {
+                        if (((pattern & 0xFFFFu) == (pattern >> 16)) & ((pattern & 0xFFu) == (pattern >> 24))) {
+                            repeat = 2;
+                            srcPatternLength = hc_count_pattern(ip + 4, iHigh, pattern) + 4;
+                        } else repeat = 1;
+                    }
+                    if (repeat == 2 && mci >= lowest) {
+                        const uint8_t* const mq = src + (mci - kHcBase);
+                        if (UNI(ld32u(mq)) == pattern) {
+                            const size_t fwd = hc_count_pattern(mq + 4, iHigh, pattern) + 4;
+                            size_t back = hc_rcount_pattern(mq, src, pattern);
+                            {   const uint32_t far = mci - (uint32_t)back;
+                                back = mci - (far > lowest ? far : lowest); }
+                            const size_t seg = back + fwd;
+                            if (seg >= srcPatternLength && fwd <= srcPatternLength) {
+                                mi = mci + (uint32_t)fwd - (uint32_t)srcPatternLength;     // :1027-1036: looked at next
+                                cursor = (int)UNI(s.w.rank[mi - kHcBase]);
+                            } else {
+                                mi = mci - (uint32_t)back;                                 // :1038-1058
+                                if (lookBack == 0) {
+                                    const size_t maxML = seg < srcPatternLength ? seg : srcPatternLength;
+                                    if ((size_t)longest < maxML) {
+                                        if (ipIndex - mi > 65535u) { walkEnds = true; break; }
+                                        longest = (int)maxML; offset = (int)(ipIndex - mi);
+                                    }
+                                    const uint32_t dp = hc_link(s, mi);
+                                    if (dp > mi) { walkEnds = true; break; }
+                                    const uint32_t at = mi - kHcBase;
+                                    mi -= dp; cursor = (int)UNI(s.w.rank[at]) - 1;
+                                    if (dp >= 65535u) { walkEnds = true; break; }
+                                } else cursor = (int)UNI(s.w.rank[mi - kHcBase]);
+                            }
+                            nextRound = true;                                          // the walk goes on somewhere else
+                            break;
+                        }
+                    }
+                }
+                if (dnk >= 65535u || k >= lastOfChain) { walkEnds = true; break; }    // the walk ends behind this candidate
+                start = k + 1;                                                        // :1065: on to the next candidate ...
+                if (start >= endLane) {                                               // ... which is beyond what this round fetched
+                    if (start >= attL) { walkEnds = true; break; }                    // (no attempts left: attempts is 0 now)
+                    mi -= dnk;
+                    cursor -= k + 1;
+                    nextRound = true;
+                }
             }
-            if (jumped) continue;
-            if (dnk >= 65535u || k >= lastOfChain) break;                          // the walk ends behind this candidate
-            mi -= dnk;                                                            // :1065
-            cursor -= k + 1;
+            if (walkEnds) break;
         }
     }
     out.len = longest; out.off = offset; out.back = sBack;
