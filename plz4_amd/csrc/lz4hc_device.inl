@@ -333,7 +333,7 @@ template <bool kD>
 DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches,
                           bool patternAnalysis, bool chainSwap)
 {
-    if (!kD && s.w.list && nbSearches >= 16)                    // levels 5..11 on an independent block: 63 candidates per round
+    if (!kD && s.w.list && nbSearches >= 8)                     // levels 4..12 on an independent block: 63 candidates per round
         return hc_find_wider_lists(s, pos, lowLimit, highLimit, longest, nbSearches, patternAnalysis, chainSwap);
     const uint8_t* const src = s.src;
     const uint8_t* const ip = src + pos;

@@ -1007,7 +1007,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         size_t chainBytes = 0, rankBytes = 0, listBytes = 0;
         if (a.level >= 3 && !a.hcEx && maxLen >= 4096 && getenv("PLZ4HIP_HC_PRE_OFF") == nullptr) {
             // levels 3..12, independent blocks: the chain of every block built up front (2 B per position): the parsers then run
-            // without their 4 M dependent table updates per 4 MiB block.  Levels 5..12 (16 candidates and more per search)
+            // without their 4 M dependent table updates per 4 MiB block.  Levels 4..12 (8 candidates and more per search)
             // also get the per-hash lists (another 8 B per position): their searches then look at up to 63 candidates per
             // round (hc_find_wider_lists).  A call whose blocks do not fit the memory set aside runs in groups of equal size.
             const int64_t stride = (int64_t)round_up((size_t)maxLen + 1, 1024);
@@ -1033,10 +1033,10 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
                 const int n = (int)((nb + g - 1) / g);
                 return (nb + n - 1) / n;
             };
-            const int perLists = (a.level >= 5 && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr) ? groups_of(budgetLists, listsPer) : 0;
+            const int perLists = (a.level >= 4 && getenv("PLZ4HIP_HC_LISTS_OFF") == nullptr) ? groups_of(budgetLists, listsPer) : 0;
             const int perChain = groups_of(budget, chainPer);
             // a group has to keep the chip busy: below 2048 blocks in flight the lists lose to the chain alone over more blocks
-            // at levels 5..9; the optimal parser's levels gain an order of magnitude and take them in any case
+            // at levels 4..9; the optimal parser's levels gain an order of magnitude and take them in any case
             lists = perLists >= 1 && (perLists == nb || perLists >= (a.level >= 10 ? 256 : 2048) || perChain < 1);
             if (lists && perLists > c->h12Bytes / listsPer) {             // try the large request first: refused -> the chain alone
                 if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));

@@ -114,7 +114,7 @@ class Emu:
         return r, dst[:max(r, 0)]
 
     def compress_hc_lists(self, src, cap, level):
-        """HC levels on the chain AND the per-hash lists built up front (levels 5..12: up to 63 candidates per round)."""
+        """HC levels on the chain AND the per-hash lists built up front (levels 4..12: up to 63 candidates per round)."""
         self.L.emu_compress_hc_lists.restype = C.c_int
         self.L.emu_compress_hc_lists.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int]
         dst = np.empty(max(cap, 1) + 64, dtype=np.uint8)

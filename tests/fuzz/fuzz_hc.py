@@ -52,7 +52,7 @@ def main(iters=400, seed=7):
                     if a != b or not np.array_equal(da, db):
                         bad += 1
                         print("MISMATCH pre", it, kind, n, lvl, cap, a, b)
-                if 5 <= lvl <= 11:                       # the 63-candidates-per-round finder on the per-hash lists (hc_find_wider_lists)
+                if 4 <= lvl <= 12:                       # the 63-candidates-per-round finder on the per-hash lists (hc_find_wider_lists)
                     b, db = emu.compress_hc_lists(src, cap, lvl)
                     tot += 1
                     if a != b or not np.array_equal(da, db):

@@ -160,8 +160,8 @@ def test_emu_hc_on_the_chain_built_up_front(ref, orc, emu):
                 assert a == b and np.array_equal(da, db), (name, src.size, lvl, cap, a, b)
 
 
-def test_emu_hc_levels_5_to_11_on_the_lists(ref, orc, emu):
-    """Levels 5..11 as the kernels run them when the per-hash lists fit the workspace: hc_find_wider_lists looks at up to 63
+def test_emu_hc_levels_4_to_11_on_the_lists(ref, orc, emu):
+    """Levels 4..11 as the kernels run them when the per-hash lists fit the workspace: hc_find_wider_lists looks at up to 63
     candidates of a chain per round, one per lane, and must pick what the one-at-a-time walk picks == LZ4_compress_HC.
     The P cases are runs of short patterns: they drive the pattern analysis inside the rounds."""
     cases = [("T", synth.text(70000)), ("Z", np.zeros(9000, np.uint8)), ("M", synth.make("M", 140000, 65536)[60000:])]
@@ -177,7 +177,7 @@ def test_emu_hc_levels_5_to_11_on_the_lists(ref, orc, emu):
             have += parts[-1].size + parts[-2].size
         cases.append(("P%d" % it, np.concatenate(parts)[:n].copy()))
     for name, src in cases:
-        for lvl in (5, 6, 7, 8, 9, 10, 11):             # 10, 11: the optimal parser, its searches with the chain swap
+        for lvl in (4, 5, 6, 7, 8, 9, 10, 11):          # 10, 11: the optimal parser, its searches with the chain swap
             for cap in (orc.bound(src.size), src.size, max(src.size // 3, 1)) if lvl in (5, 9, 11) else (orc.bound(src.size),):
                 a, da = ref.compress_hc(src, cap, lvl)
                 b, db = emu.compress_hc_lists(src, cap, lvl)
