@@ -169,19 +169,20 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
     uint32_t chainPos = 0;       // chain swap (:964-987): the walk follows the chain of position candidate + chainPos
     HcMatch out;
     const uint32_t head = UNI((uint32_t)s.w.pre[pos]);
+    const uint32_t rank0 = UNI(s.w.rank[pos]);               // (requested with the head: one memory round trip)
     if (head) {
         uint32_t mi = ipIndex - head;                        // the current candidate ...
-        int cursor = (int)UNI(s.w.rank[pos]) - 1;            // ... and where it sits in the list
+        int cursor = (int)rank0 - 1;                         // ... and where it sits in the list
         while (mi >= lowest && attempts > 0) {
             // lane k: the candidate k places below the current one in the chain (list[cursor - k]); 64 entries are fetched so
             // that every one of the 63 candidates knows its link (the distance to the next candidate)
-            LV(uint32_t, q); LV(int, fl); LV(int, pat);
+            LV(uint32_t, q); LV(int, fl); LV(int, pat); LV(uint32_t, ent);
             {
                 const int curL = cursor;
-                LANES({ const uint32_t e = (curL - LANE >= -8) ? s.w.list[curL - LANE] : 0x80000000u; q[I_] = e & 0x7FFFFFFFu; fl[I_] = (int)(e >> 31); })
+                LANES({ const uint32_t e = (curL - LANE >= -8) ? s.w.list[curL - LANE] : 0x80000000u; ent[I_] = e; q[I_] = e & 0x7FFFFFFFu; fl[I_] = (int)(e >> 31); })
             }
-            LV(uint32_t, qn); LV(int, fln);
-            LANES({ qn[I_] = SHFL(q, LANE + 1); fln[I_] = SHFL(fl, LANE + 1); })
+            LV(uint32_t, qn);
+            LANES({ qn[I_] = SHFL(ent, LANE + 1) & 0x7FFFFFFFu; })
             // a candidate exists while the chain has not ended above it, it is inside the window, and attempts are left; its
             // link is what the chain table would hold (saturated at 65535, which also ends the walk, :1065 -> :918)
             const uint64_t ends = BALLOT(fl[I_] != 0);                          // the chain's first position sits in this lane
