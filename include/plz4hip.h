@@ -25,8 +25,8 @@
  * Memory: the host-buffer calls keep their pinned host + device staging (up to 3 chunks of <= 4 GiB) and the HC levels their
  * workspaces between calls; plz4hip_ctx_trim gives them back.  The HC workspaces are sized by the call: levels 4..12 on
  * independent blocks keep 10 bytes per input byte of the blocks in flight (chains + per-hash lists; level 12 another 8) and may
- * take up to three quarters of the device memory that is free when the call arrives (half, at most 96 GiB, for level 12 and for
- * the chain alone); a call whose blocks do not fit runs in groups.  A caller that needs the memory for itself allocates first or
+ * take up to three quarters of the device memory that is free when the call arrives (half, at most 96 GiB, for level 3's
+ * chain alone); a call whose blocks do not fit runs in groups.  A caller that needs the memory for itself allocates first or
  * sets PLZ4HIP_HC_BUDGET_GIB.
  */
 #ifndef PLZ4HIP_H

@@ -931,33 +931,49 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
     pl->perBlock = (size_t)pl->chainStride * 2 + (size_t)pl->chainStride * 4 + ((size_t)pl->chainStride + 8) * 4 + (size_t)kHcHashEntries * 4 + (size_t)pl->fStride * 8;
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
-    size_t budget = (freeB + c->h12Bytes) / 2;
-    if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
+    // up to three quarters of what is free (and whatever the ctx holds already): the parser runs one wave per block, so the more
+    // blocks a group has (up to three waves per SIMD: 3072), the better its latency is hidden -- 4096 blocks in two groups of 2048
+    // instead of four of 1024: 1418 -> 1664 MiB/s.  plz4hip_ctx_trim gives the memory back.
+    size_t budget = (freeB + c->h12Bytes) / 4 * 3;
+    if (const char* v = getenv("PLZ4HIP_HC_BUDGET_GIB")) { const long g = atol(v); if (g >= 1) budget = (size_t)g << 30; }
+    if (budget < c->h12Bytes) budget = c->h12Bytes;
     int64_t grp = (int64_t)(budget / pl->perBlock);
     if (const char* v = getenv("PLZ4HIP_HC12_GROUP")) { const int gv = atoi(v); if (gv >= 1) grp = gv; }
     if (grp < 1) grp = 1;
     if (grp > nBlocks) grp = nBlocks;
-    pl->group = (int)grp;
     if (!c->h12ParseWaves) {
         int per = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc12_parse, 64, 0) != hipSuccess || per < 1) per = 8;
         c->h12ParseWaves = c->cus * per;
     }
-    // [0, 256): the error flag (zeroed when the workspace is allocated, sticky); the chains start behind it
-    pl->offRank = 256 + round_up((size_t)pl->group * (size_t)pl->chainStride * 2, 256);
-    pl->offList = pl->offRank + round_up((size_t)pl->group * (size_t)pl->chainStride * 4, 256);
-    pl->offOffsets = pl->offList + round_up((size_t)pl->group * ((size_t)pl->chainStride + 8) * 4, 256);
-    pl->offF = pl->offOffsets + round_up((size_t)pl->group * (size_t)kHcHashEntries * 4, 256);
-    pl->offWs = pl->offF + round_up((size_t)pl->group * (size_t)pl->fStride * 8, 256);
-    pl->offErr = 0;
-    pl->total = pl->offWs + round_up((size_t)c->h12ParseWaves * kHc12WsGlobalBytes, 256);
-    if (pl->total > c->h12Bytes) {
+    for (;;) {
+        {   // groups of equal size: what is allocated is what one of them needs, whatever the budget would allow
+            const int64_t nGroups = (nBlocks + grp - 1) / grp;
+            pl->group = (int)((nBlocks + nGroups - 1) / nGroups);
+        }
+        // [0, 256): the error flag (zeroed when the workspace is allocated, sticky); the chains start behind it
+        pl->offRank = 256 + round_up((size_t)pl->group * (size_t)pl->chainStride * 2, 256);
+        pl->offList = pl->offRank + round_up((size_t)pl->group * (size_t)pl->chainStride * 4, 256);
+        pl->offOffsets = pl->offList + round_up((size_t)pl->group * ((size_t)pl->chainStride + 8) * 4, 256);
+        pl->offF = pl->offOffsets + round_up((size_t)pl->group * (size_t)kHcHashEntries * 4, 256);
+        pl->offWs = pl->offF + round_up((size_t)pl->group * (size_t)pl->fStride * 8, 256);
+        pl->offErr = 0;
+        pl->total = pl->offWs + round_up((size_t)c->h12ParseWaves * kHc12WsGlobalBytes, 256);
+        if (getenv("PLZ4HIP_VERBOSE"))
+            fprintf(stderr, "plz4hip: level 12, %d blocks: free %zu MiB, held %zu MiB, groups of %d (%zu MiB)\n", nBlocks, freeB >> 20, c->h12Bytes >> 20, pl->group, pl->total >> 20);
+        if (pl->total <= c->h12Bytes) break;
         if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));          // nothing may still use the old workspace
         if (c->d_h12) hipFree(c->d_h12);
         c->d_h12 = nullptr; c->h12Bytes = 0;
-        if (hipMalloc((void**)&c->d_h12, pl->total) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "level-12 workspace");
-        c->h12Bytes = pl->total;
-        HIPCHK(c, hipMemset(c->d_h12, 0, 256));
+        if (hipMalloc((void**)&c->d_h12, pl->total) == hipSuccess) {
+            c->h12Bytes = pl->total;
+            HIPCHK(c, hipMemset(c->d_h12, 0, 256));
+            break;
+        }
+        (void)hipGetLastError();
+        c->d_h12 = nullptr;
+        if (grp <= 1) return fail(c, PLZ4HIP_E_NOMEM, "level-12 workspace");
+        grp = (grp + 1) / 2;                                                  // refused: smaller groups
     }
     return PLZ4HIP_OK;
 }
@@ -1013,7 +1029,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             const int64_t stride = (int64_t)round_up((size_t)maxLen + 1, 1024);
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
-            size_t budget = (freeB + c->h12Bytes) / 2;                   // the chain alone: as plan_h12
+            size_t budget = (freeB + c->h12Bytes) / 2;                   // the chain alone: half of what is free, at most 96 GiB
             if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
             // the lists are worth more memory than that: these kernels live on the number of blocks in flight (7 waves per SIMD
             // fit), and 4096 blocks of 4 MiB with their lists (40 MiB each) are 160 GiB -- up to three quarters of what is free;
