@@ -1411,6 +1411,9 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
     if (dictMode && dj->prevTail && dj->prevTailLen > 65536) return fail(c, PLZ4HIP_E_ARG, "prevTail longer than 64 KiB");
 
     size_t kChunkBytes = (size_t)4 << 30;      // x kSlots in flight (smaller chunks starve the encoder's wave slots); pinned host + device staging stay allocated until plz4hip_ctx_trim / destroy
+    // the HC levels run one chunk at a time (below) and live on the number of blocks in flight: one chunk of three times the
+    // size (4 MiB blocks: 1024 instead of 341 per chunk) for the same staging memory
+    if (hcMode) kChunkBytes *= plz4hip_ctx::kSlots;
     if (const char* v = getenv("PLZ4HIP_HOST_CHUNK_MB")) { const long mb = atol(v); if (mb > 0) kChunkBytes = (size_t)mb << 20; }   // tests: force many chunks
     const size_t gap = (dictMode && (mode == 0 || mode == 2)) ? 65536 : 0;     // encoders with a dictionary / linked blocks: room for the external segment
     int cb = nBlocks;
