@@ -22,7 +22,8 @@
  * puts the calling thread's current HIP device back before it returns (goroutines migrate between OS threads); use one
  * ctx per writer/reader for concurrency, one per device for several GPUs (section D).  plz4hip_last_error returns the
  * calling thread's own copy of the text (valid until that thread asks again).
- * Memory: the host-buffer calls keep their pinned host + device staging (up to 3 chunks of <= 4 GiB) and the HC levels their
+ * Memory: the host-buffer calls keep their pinned host + device staging (up to 3 chunks of <= 4 GiB; one of <= 12 GiB at the HC
+ * levels, which run a chunk at a time) and the HC levels their
  * workspaces between calls; plz4hip_ctx_trim gives them back.  The HC workspaces are sized by the call: levels 4..12 on
  * independent blocks keep 10 bytes per input byte of the blocks in flight (chains + per-hash lists; level 12 another 8) and may
  * take up to three quarters of the device memory that is free when the call arrives (half, at most 96 GiB, for level 3's
