@@ -167,6 +167,10 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
     int offset = 0, sBack = 0, attempts = nbSearches, repeat = 0;
     size_t srcPatternLength = 0;
     uint32_t chainPos = 0;       // chain swap (:964-987): the walk follows the chain of position candidate + chainPos
+    // the 8 bytes behind a candidate's prefix come with the prefix: a candidate that differs from us within them has a known
+    // forward length (4..11) -- no counting loop for it, and no event at all when that length (+ lookBack) cannot reach `longest`
+    const bool useFw = iHigh - ip >= 12;
+    const uint64_t ip64 = useFw ? ld64u(ip + 4) : 0ull;
     HcMatch out;
     const uint32_t head = UNI((uint32_t)s.w.pre[pos]);
     const uint32_t rank0 = UNI(s.w.rank[pos]);               // (requested with the head: one memory round trip)
@@ -199,17 +203,18 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
             })
             // the candidates' 4-byte prefixes, once per round; the 2 bytes at `longest - 1` (:921) again whenever `longest` grows
             // (both requested together the first time: one memory round trip)
-            LV(int, pfx); LV(int, pass);
+            LV(int, pfx); LV(int, pass); LV(int, fw);
             {
                 const uint32_t ip16 = UNI((uint32_t)ld16u(iLow + longest - 1));
                 const int nv = nvalid, L = longest;
                 LANES({
-                    pfx[I_] = 0; pass[I_] = 0; pat[I_] = 0;
+                    pfx[I_] = 0; pass[I_] = 0; pat[I_] = 0; fw[I_] = 9;                   // 0..7: differs there; 8: the 8 bytes are equal; 9: not looked at
                     if (LANE < nv) {
                         const uint8_t* mp = src + q[I_] - cp;
                         const uint32_t m16 = ld16u(mp - lookBack + L - 1);
+                        if (useFw) { const uint64_t x = ld64u(mp + 4) ^ ip64; fw[I_] = x ? (ctz64(x) >> 3) : 8; }
                         pfx[I_] = ld32u(mp) == pattern;
-                        pass[I_] = pfx[I_] && m16 == ip16;
+                        pass[I_] = pfx[I_] && m16 == ip16 && !(fw[I_] < 8 && 4 + fw[I_] + lookBack < L);
                         pat[I_] = patternAnalysis && dn[I_] == 1u && cp == 0;
                     }
                 })
@@ -227,7 +232,8 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                     const int L = longest, st = start, en = endLane;
                     LANES({
                         pass[I_] = 0;
-                        if (LANE >= st && LANE < en && pfx[I_]) pass[I_] = ld16u(src + q[I_] - cp - lookBack + L - 1) == ip16;
+                        if (LANE >= st && LANE < en && pfx[I_] && !(fw[I_] < 8 && 4 + fw[I_] + lookBack < L))
+                            pass[I_] = ld16u(src + q[I_] - cp - lookBack + L - 1) == ip16;
                     })
                     passFor = longest;
                 }
@@ -249,7 +255,10 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                 const uint8_t* const mp = src + (mi - kHcBase);
                 if (RL(pass, k)) {                                                    // :933-939
                     const int back = lookBack ? hc_count_back(ip, mp, iLow, src) : 0;
-                    int mlen = kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
+                    const int fwk = RL(fw, k);
+                    int mlen = fwk < 8 ? kMinMatch + fwk
+                             : fwk == 8 ? kMinMatch + 8 + hc_count(ip + kMinMatch + 8, mp + kMinMatch + 8, iHigh)
+                             : kMinMatch + hc_count(ip + kMinMatch, mp + kMinMatch, iHigh);
                     mlen -= back;
                     if (mlen > longest) { longest = mlen; offset = (int)(ipIndex - mi); sBack = back; }
                     if (chainSwap && mlen == longest && mi + (uint32_t)longest <= ipIndex) {               // :964-987, as in hc_find_wider
