@@ -20,6 +20,7 @@
 __device__ unsigned long long plz4_stats[24];
 #endif
 #include "lz4_device.inl"
+#include "lz4_seq_device.inl"
 #include "lz4hc_device.inl"
 #include "lz4hc12_device.inl"
 
@@ -61,6 +62,12 @@ struct CodecArgs {
     int32_t*        h12Err;                                  // set when a kernel gives up (spin guard)
     int             rawMode;                                 // parse kernel: 1 = raw LZ4 blocks (dstCap per block), 0 = frame records
     int             h12Gather, h12Idle;                      // search kernel: lanes a phase / the queue waits for before its section runs
+    // level 1 in stages (lz4_seq_device.inl): parse -> sizes -> scan -> write -> finish over the group [blk0, blk0 + nBlocks);
+    // the workspace is indexed by the block's number inside the group
+    SeqInfo*        l1Info;                                  // per block
+    uint64_t*       l1Seq;      int64_t l1SeqStride;         // sequence records, entries per block
+    uint32_t*       l1ChunkBytes; uint32_t* l1ChunkOff; int l1MaxChunks;   // per block: bytes of / before every chunk of 1024 sequences
+    int             l1MaxLen;                                // what the workspace was sized for
 };
 
 __device__ __forceinline__ int next_block(uint32_t* q)
@@ -125,6 +132,98 @@ template <int W> __global__ __launch_bounds__(64 * W) void k_encode_rec(CodecArg
         }
         if ((threadIdx.x & 63u) == 0) { st32u(rec, word); a.result[i] = len; }
     }
+}
+
+// ---- level 1 in stages (independent blocks up to 4 MiB, no dictionary): lz4_seq_device.inl ------------------------------------
+// k_l1_parse: persistent, one wave per block, the hash table in LDS -- the only serial stage; it writes one 8-byte record per
+// sequence.  The others are plain data-parallel kernels, one lane per sequence, any number of waves per block, no LDS.
+template <int W> __global__ __launch_bounds__(64 * W) void k_l1_parse(CodecArgs a)
+{
+    ENC_WAVE_TABLE(lds);
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int gi = a.blk0 + i;
+        const int n  = block_len(a, gi);
+        int lastAnchor = 0, nseq = -1;                                       // -1: a block the workspace was not sized for
+        if (n >= 0 && n <= a.l1MaxLen)
+            nseq = wave_parse_l1(a.src + (int64_t)gi * a.srcStride, n, lds, a.l1Seq + (int64_t)i * a.l1SeqStride, &lastAnchor);
+        if ((threadIdx.x & 63u) == 0) { SeqInfo inf; inf.nseq = nseq; inf.lastAnchor = lastAnchor; inf.total = 0; inf.stored = 0; a.l1Info[i] = inf; }
+    }
+}
+
+// grid (waves per block / 4, blocks of the group): bytes of every chunk of 1024 sequences
+__global__ __launch_bounds__(256) void k_l1_sizes(CodecArgs a)
+{
+    const int i = blockIdx.y, wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6), nW = gridDim.x * 4;
+    const int nseq = a.l1Info[i].nseq;
+    if (nseq <= 0) return;
+    const int gi = a.blk0 + i;
+    const uint8_t*  s   = a.src + (int64_t)gi * a.srcStride;
+    const uint64_t* seq = a.l1Seq + (int64_t)i * a.l1SeqStride;
+    const int nChunks = (nseq + kSeqChunk - 1) / kSeqChunk;
+    for (int c = wave; c < nChunks; c += nW) {
+        const uint32_t v = seq_emit_sizes(s, seq, nseq, c);
+        if ((threadIdx.x & 63u) == 0) a.l1ChunkBytes[(int64_t)i * a.l1MaxChunks + c] = v;
+    }
+}
+
+// one wave per block: where every chunk goes, the block's size, liblz4's limitedOutput verdict; raw mode: result[i] = size or 0;
+// records (blk.CompressToBlk, blk/blk.go:69-109): the size word (stored iff the encoder returned 0) and, without block
+// checksums, the record length
+__global__ __launch_bounds__(256) void k_l1_scan(CodecArgs a)
+{
+    const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i >= a.nBlocks) return;
+    const int gi = a.blk0 + i;
+    const int n  = block_len(a, gi);
+    SeqInfo inf = a.l1Info[i];
+    const int cap = a.rawMode ? (a.dstCap ? a.dstCap[gi] : a.dstCapAll) : a.bsz;     // records: capacity == bsz (blk/blk.go:73)
+    int total = 0;
+    if (inf.nseq >= 0)
+        total = seq_emit_scan(a.l1ChunkBytes + (int64_t)i * a.l1MaxChunks, a.l1ChunkOff + (int64_t)i * a.l1MaxChunks, inf.nseq, inf.lastAnchor, n, cap);
+    if ((threadIdx.x & 63u) == 0) {
+        inf.total = total; inf.stored = (total == 0);
+        a.l1Info[i] = inf;
+        if (a.rawMode) a.result[gi] = total;
+        else {
+            const int c = total ? total : n;                                          // ErrCompress -> stored raw (blk.go:78-92)
+            st32u(a.dst + (int64_t)gi * a.dstStride, total ? ((uint32_t)c & 0x7FFFFFFFu) : (0x80000000u | ((uint32_t)n & 0x7FFFFFFFu)));
+            if (!a.blockChecksum) a.result[gi] = c + 4;
+        }
+    }
+}
+
+// grid as k_l1_sizes: every chunk written at its place; a record whose encoder returned 0 gets the plaintext instead
+__global__ __launch_bounds__(256) void k_l1_write(CodecArgs a)
+{
+    const int i = blockIdx.y, wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6), nW = gridDim.x * 4;
+    const SeqInfo inf = a.l1Info[i];
+    const int gi = a.blk0 + i;
+    const int n  = block_len(a, gi);
+    const uint8_t* s   = a.src + (int64_t)gi * a.srcStride;
+    uint8_t*       out = a.dst + (int64_t)gi * a.dstStride + (a.rawMode ? 0 : 4);
+    if (inf.total > 0) {
+        const uint64_t* seq = a.l1Seq + (int64_t)i * a.l1SeqStride;
+        const int nChunks = (inf.nseq + kSeqChunk - 1) / kSeqChunk;
+        for (int c = wave; c < (nChunks ? nChunks : 1); c += nW)
+            seq_emit_write(s, n, seq, inf.nseq, inf.lastAnchor, c, nChunks ? a.l1ChunkOff[(int64_t)i * a.l1MaxChunks + c] : 0u, out);
+    } else if (!a.rawMode && n > 0) {
+        const int slice = (((n + nW - 1) / nW) + 15) & ~15;
+        const int off = wave * slice;
+        if (off < n) wave_copy(out + off, s + off, min_(slice, n - off));
+    }
+}
+
+// records with block checksums: xxh32 over the payload as stored (blk.go:98-102), one wave per block
+__global__ __launch_bounds__(256) void k_l1_finish(CodecArgs a)
+{
+    const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    if (i >= a.nBlocks) return;
+    const int gi = a.blk0 + i;
+    const SeqInfo inf = a.l1Info[i];
+    const int c = inf.total ? inf.total : block_len(a, gi);
+    uint8_t* rec = a.dst + (int64_t)gi * a.dstStride;
+    const uint32_t x = wave_xxh32(rec + 4, c);
+    if ((threadIdx.x & 63u) == 0) { st32u(rec + 4 + c, x); a.result[gi] = c + 8; }
 }
 
 // One level-1 block under a dictionary context and/or after another linked block.  Every input block of such a call has
@@ -767,8 +866,10 @@ struct plz4hip_ctx {
     int          cus = 0;
     int          encWaves = 0, decWaves = 0;
     // host-API staging (grown on demand): a ring of chunks in flight, each with pinned host memory, device memory and a stream
+    // level 1 in stages: sequence records + chunk tables of one group of blocks (launch_l1)
+    struct L1Ws { uint8_t* d = nullptr; size_t bytes = 0; };
     struct HostSlot { uint8_t* h = nullptr; size_t hcap = 0; uint8_t* d = nullptr; size_t dcap = 0; hipStream_t s = nullptr;
-                      hipEvent_t evData = nullptr, evHash = nullptr; bool hashBusy = false; };
+                      hipEvent_t evData = nullptr, evHash = nullptr; bool hashBusy = false; L1Ws l1; };
     plz4hip_xxh32_stream* contentHash = nullptr;   // plz4hip_ctx_set_content_hash
     static constexpr int kSlots = 3;
     HostSlot     slot[kSlots];
@@ -779,6 +880,10 @@ struct plz4hip_ctx {
     // job on another stream waits for that event on the device (no host block).
     hipEvent_t   hcDone = nullptr; hipStream_t hcStream = nullptr; bool hcPending = false;
     hipStream_t  hashStream = nullptr;   // the streaming content checksum runs here, beside the codec kernels
+    // the level-1 workspace of the device-resident calls (the host-buffer calls have one per staging slot): one job at a time,
+    // ordered across streams on the device like the HC workspaces
+    L1Ws         l1;
+    hipEvent_t   l1Done = nullptr; hipStream_t l1Stream = nullptr; bool l1Pending = false;
 };
 
 // == clz4.DictCtx (clz4.go:96-120): a private device copy of the last 64 KiB of the dictionary + the LZ4_loadDictSlow table.
@@ -1110,6 +1215,85 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     return hc_leave(c, s);
 }
 
+// Enqueue one level-1 call of nb independent blocks without dictionary (a: everything but queue / workspace filled in) on s.
+// rawMode: LZ4 blocks (result = bytes or 0), else records.  Blocks up to 4 MiB run in stages (lz4_seq_device.inl): the
+// workspace holds 8 bytes per possible sequence -- 2 bytes per input byte -- of one group of blocks; a call that does not fit
+// the memory set aside (half of what is free; PLZ4HIP_L1_BUDGET_GIB) runs in groups of equal size.  ws: the workspace to use
+// (a staging slot's own, always used from that slot's stream) or null for the ctx's, which is ordered across streams.
+// Larger blocks (raw block API only) and calls that do not say how long their blocks are keep the fused kernels.
+int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws)
+{
+    hipError_t e;
+    a.rawMode = rawMode; a.blk0 = 0; a.nBlocks = nb;
+    const bool shared = (ws == nullptr);
+    if (shared) ws = &c->l1;
+    bool fused = maxLen <= 0 || maxLen > kSeqMaxBlock || getenv("PLZ4HIP_L1_FUSED") != nullptr;
+    const size_t seqStride = round_up((size_t)(maxLen > 0 ? maxLen : 0) / 4 + 2, 64);
+    const int    maxChunks = (int)((seqStride + kSeqChunk - 1) / kSeqChunk);
+    const size_t perBlock  = sizeof(SeqInfo) + (size_t)maxChunks * 8 + seqStride * 8;
+    const auto need_for = [&](int per) { return round_up((size_t)per * sizeof(SeqInfo), 256) + 2 * round_up((size_t)per * maxChunks * 4, 256) + (size_t)per * seqStride * 8; };
+    int per = nb;
+    if (!fused && need_for(nb) > ws->bytes) {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
+        size_t budget = (freeB + ws->bytes) / 2;
+        if (const char* v = getenv("PLZ4HIP_L1_BUDGET_GIB")) { const long g = atol(v); if (g >= 1) budget = (size_t)g << 30; }
+        if (const char* v = getenv("PLZ4HIP_L1_BUDGET_MIB")) { const long g = atol(v); if (g >= 1) budget = (size_t)g << 20; }   // tests: force groups
+        if (budget < ws->bytes) budget = ws->bytes;
+        int64_t grp = (int64_t)(budget / (perBlock + 64));
+        if (grp > nb) grp = nb;
+        while (grp >= 1) {
+            const int nGroups = (int)((nb + grp - 1) / grp);
+            per = (nb + nGroups - 1) / nGroups;
+            if (need_for(per) <= ws->bytes) break;
+            if (shared && c->l1Pending) HIPCHK(c, hipEventSynchronize(c->l1Done));     // nothing may still use the old workspace
+            else if (!shared) HIPCHK(c, hipStreamSynchronize(s));
+            if (ws->d) hipFree(ws->d);
+            ws->d = nullptr; ws->bytes = 0;
+            if (hipMalloc((void**)&ws->d, need_for(per)) == hipSuccess) { ws->bytes = need_for(per); break; }
+            (void)hipGetLastError();
+            ws->d = nullptr;
+            grp = grp / 2;                                                              // refused: smaller groups
+        }
+        if (grp < 1) fused = true;                                                      // not even one block: the fused kernels need no workspace
+        if (getenv("PLZ4HIP_VERBOSE"))
+            fprintf(stderr, "plz4hip: level 1, %d blocks of <= %d: free %zu MiB, workspace %zu MiB, groups of %d%s\n", nb, maxLen, freeB >> 20, ws->bytes >> 20, per, fused ? " (fused)" : "");
+    }
+    if (fused) {
+        a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+        if (rawMode) ENC_LAUNCH(k_encode_raw, nb, c, s, a); else ENC_LAUNCH(k_encode_rec, nb, c, s, a);
+        HIPCHK(c, hipGetLastError());
+        return PLZ4HIP_OK;
+    }
+    if (shared && c->l1Pending && c->l1Stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->l1Done, 0));
+    a.l1MaxLen = maxLen; a.l1SeqStride = (int64_t)seqStride; a.l1MaxChunks = maxChunks;
+    a.l1Info = (SeqInfo*)ws->d;
+    a.l1ChunkBytes = (uint32_t*)(ws->d + round_up((size_t)per * sizeof(SeqInfo), 256));
+    a.l1ChunkOff   = (uint32_t*)((uint8_t*)a.l1ChunkBytes + round_up((size_t)per * maxChunks * 4, 256));
+    a.l1Seq        = (uint64_t*)((uint8_t*)a.l1ChunkOff + round_up((size_t)per * maxChunks * 4, 256));
+    for (int g0 = 0; g0 < nb; g0 += per) {
+        const int ng = nb - g0 < per ? nb - g0 : per;
+        a.blk0 = g0; a.nBlocks = ng;
+        a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+        ENC_LAUNCH(k_l1_parse, ng, c, s, a);
+        // emit: waves per block so that a small call still spreads over the chip
+        int wg = (16384 / ng) / 4;
+        if (wg > (maxChunks + 3) / 4) wg = (maxChunks + 3) / 4;
+        if (wg < 1) wg = 1;
+        hipLaunchKernelGGL(k_l1_sizes, dim3(wg, ng), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_l1_scan, dim3((ng + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_l1_write, dim3(wg, ng), dim3(256), 0, s, a);
+        if (!rawMode && a.blockChecksum) hipLaunchKernelGGL(k_l1_finish, dim3((ng + 3) / 4), dim3(256), 0, s, a);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (shared) {
+        if (!c->l1Done) HIPCHK(c, hipEventCreateWithFlags(&c->l1Done, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->l1Done, s));
+        c->l1Pending = true; c->l1Stream = s;
+    }
+    return PLZ4HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1184,9 +1368,13 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
         if (sl.evHash) hipEventDestroy(sl.evHash);
         if (sl.h) hipHostFree(sl.h);
         if (sl.d) hipFree(sl.d);
+        if (sl.l1.d) hipFree(sl.l1.d);
     }
     if (c->d_hc) hipFree(c->d_hc);
     if (c->d_h12) hipFree(c->d_h12);
+    if (c->l1Pending) hipEventSynchronize(c->l1Done);
+    if (c->l1.d) hipFree(c->l1.d);
+    if (c->l1Done) hipEventDestroy(c->l1Done);
     if (c->hcDone) hipEventDestroy(c->hcDone);
     if (c->hashStream) { hipStreamSynchronize(c->hashStream); hipStreamDestroy(c->hashStream); }
     delete c;
@@ -1203,7 +1391,10 @@ int plz4hip_ctx_trim(plz4hip_ctx* c)
         if (sl.s) HIPCHK(c, hipStreamSynchronize(sl.s));
         if (sl.h) { hipHostFree(sl.h); sl.h = nullptr; sl.hcap = 0; }
         if (sl.d) { hipFree(sl.d); sl.d = nullptr; sl.dcap = 0; }
+        if (sl.l1.d) { hipFree(sl.l1.d); sl.l1.d = nullptr; sl.l1.bytes = 0; }
     }
+    if (c->l1Pending) { HIPCHK(c, hipEventSynchronize(c->l1Done)); c->l1Pending = false; }
+    if (c->l1.d) { hipFree(c->l1.d); c->l1.d = nullptr; c->l1.bytes = 0; }
     if (c->d_hc) { hipFree(c->d_hc); c->d_hc = nullptr; c->hcWaves = 0; }
     if (c->d_h12) { hipFree(c->d_h12); c->d_h12 = nullptr; c->h12Bytes = 0; }
     return PLZ4HIP_OK;
@@ -1237,10 +1428,7 @@ int plz4hip_dev_compress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t s
     a.result = result; a.nBlocks = nBlocks;
     a.dictLen = -1; a.prevTailLen = -1;
     if (is_hc_level(level)) { a.level = level; return launch_hc(c, s, a, nBlocks, maxLen, 1); }
-    hipError_t e; a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-    ENC_LAUNCH(k_encode_raw, nBlocks, c, s, a);
-    HIPCHK(c, hipGetLastError());
-    return PLZ4HIP_OK;
+    return launch_l1(c, s, a, nBlocks, maxLen, 1, nullptr);              // (maxLen <= 0: lengths unknown to the host -> fused kernels)
 }
 
 int plz4hip_dev_decompress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
@@ -1282,12 +1470,8 @@ int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes
     if (is_hc_level(level)) {
         a.level = level;
         return launch_hc(c, s, a, nBlocks, bsz, 0);
-    } else {
-        hipError_t e; a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-        ENC_LAUNCH(k_encode_rec, nBlocks, c, s, a);
     }
-    HIPCHK(c, hipGetLastError());
-    return PLZ4HIP_OK;
+    return launch_l1(c, s, a, nBlocks, bsz, 0, nullptr);
 }
 
 static int move_slices(int maxLen) { const int s = (maxLen + 256 * 16 * 8 - 1) / (256 * 16 * 8); return s < 1 ? 1 : s; }
@@ -1491,13 +1675,13 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         switch (mode) {
         case 0: if (hcMode) { if (int rc = launch_hc(c, s, a, nb, maxIn, 1)) return rc; }
                 else if (dictMode) ENC_LAUNCH(k_encode_raw_dict, nb, c, s, a);
-                else ENC_LAUNCH(k_encode_raw, nb, c, s, a); break;
+                else { if (int rc = launch_l1(c, s, a, nb, maxIn, 1, &sl.l1)) return rc; } break;
         case 1: if (dictMode) hipLaunchKernelGGL(k_decode_raw_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
                 else hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a); break;
         case 2: a.dstCap = nullptr;
                 if (hcMode) { if (int rc = launch_hc(c, s, a, nb, maxIn, 0)) return rc; }
                 else if (dictMode) ENC_LAUNCH(k_encode_rec_dict, nb, c, s, a);
-                else ENC_LAUNCH(k_encode_rec, nb, c, s, a); break;
+                else { if (int rc = launch_l1(c, s, a, nb, maxIn, 0, &sl.l1)) return rc; } break;
         case 3: a.dstCap = nullptr;
                 if (dictMode && dj->linked) hipLaunchKernelGGL(k_decode_rec_linked, dim3(grid_for(nCh, c->decWaves)), dim3(64), 0, s, a);
                 else if (dictMode) hipLaunchKernelGGL(k_decode_rec_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);

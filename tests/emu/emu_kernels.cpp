@@ -3,6 +3,7 @@
 // Test infrastructure only: built into tests/emu/_build/, never loaded by plz4_amd, not a CPU fallback.
 #define PLZ4_EMU 1
 #include "../../plz4_amd/csrc/lz4_device.inl"
+#include "../../plz4_amd/csrc/lz4_seq_device.inl"
 #include "../../plz4_amd/csrc/lz4hc_device.inl"
 #include <stdlib.h>
 
@@ -14,10 +15,39 @@ extern "C" {
 void emu_set_descending(int d) { plz4_emu_descending = d; }
 void emu_set_old_dict(int d) { plz4_emu_old_dict = d; }
 
-int emu_encode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
+// the fused encoder (lz4_device.inl): what the kernels run for blocks above 4 MiB and, in its external-segment mode, for
+// dictionaries / linked blocks
+int emu_encode_block_fused(const uint8_t* src, int n, uint8_t* dst, int cap)
 {
     static thread_local uint32_t lds[plz4::kHashBytes / 4];
     return plz4::wave_encode_block(src, n, dst, cap, lds);
+}
+
+// parse -> sizes -> scan -> write (lz4_seq_device.inl), stage by stage as the kernels run them; nseqOut: sequences found
+int emu_encode_block_seq(const uint8_t* src, int n, uint8_t* dst, int cap, int* nseqOut)
+{
+    using namespace plz4;
+    static thread_local uint32_t lds[kHashBytes / 4];
+    if (n < 0 || n > kSeqMaxBlock) return -1;
+    uint64_t* seq = (uint64_t*)malloc((size_t)seq_capacity(n) * 8);
+    int lastAnchor = 0;
+    const int nseq = wave_parse_l1(src, n, lds, seq, &lastAnchor);
+    if (nseqOut) *nseqOut = nseq;
+    const int nChunks = (nseq + kSeqChunk - 1) / kSeqChunk;
+    uint32_t* cb = (uint32_t*)malloc((size_t)(nChunks + 1) * 4);
+    uint32_t* co = (uint32_t*)malloc((size_t)(nChunks + 1) * 4);
+    co[0] = 0;
+    for (int c = 0; c < nChunks; ++c) cb[c] = seq_emit_sizes(src, seq, nseq, c);
+    const int total = seq_emit_scan(cb, co, nseq, lastAnchor, n, cap);
+    if (total > 0) for (int c = 0; c < (nChunks ? nChunks : 1); ++c) seq_emit_write(src, n, seq, nseq, lastAnchor, c, co[c], dst);
+    free(seq); free(cb); free(co);
+    return total;
+}
+
+int emu_encode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
+{
+    if (n <= plz4::kSeqMaxBlock) return emu_encode_block_seq(src, n, dst, cap, nullptr);
+    return emu_encode_block_fused(src, n, dst, cap);
 }
 
 // Both builds of the decoder's vector path: the LDS-staged one the record kernels run, and the one that copies through

@@ -12,7 +12,7 @@ from orclib import ROOT, _ptr, u8p
 
 EMU_SRC = os.path.join(ROOT, "tests", "emu", "emu_kernels.cpp")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "_build", "libemu.so")
-DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "lz4hc_device.inl", "lz4hc12_device.inl", "wave.h")]
+DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "lz4_seq_device.inl", "lz4hc_device.inl", "lz4hc12_device.inl", "wave.h")]
 
 
 def build_emu():
@@ -79,8 +79,17 @@ class Emu:
         self.L.emu_set_descending(int(d))
 
     def compress_fast(self, src: np.ndarray, cap: int):
+        """Level 1 as the kernels run it: parse -> emit for blocks up to 4 MiB, the fused encoder above."""
         dst = np.empty(max(cap, 1) + 32, dtype=np.uint8)
         r = int(self.L.emu_encode_block(_ptr(src), src.size, _ptr(dst), cap))
+        return r, dst[:max(r, 0)]
+
+    def compress_fast_fused(self, src: np.ndarray, cap: int):
+        """The fused encoder of lz4_device.inl (blocks above 4 MiB; dictionary modes run it in its external-segment form)."""
+        self.L.emu_encode_block_fused.restype = C.c_int
+        self.L.emu_encode_block_fused.argtypes = [u8p, C.c_int, u8p, C.c_int]
+        dst = np.empty(max(cap, 1) + 32, dtype=np.uint8)
+        r = int(self.L.emu_encode_block_fused(_ptr(src), src.size, _ptr(dst), cap))
         return r, dst[:max(r, 0)]
 
     def decompress_safe(self, src: np.ndarray, cap: int):
