@@ -79,6 +79,37 @@ DEV int win20_fwd(const Win20& p, const Win20& c)
 // seq[] (at most seq_capacity(n)).  Returns their number; *lastAnchor = where the last literals start (lz4.c:1302).
 // `tab` = 16 KiB of LDS owned by this wave.  Two kinds of batch as in wave_encode_block_tt (lz4_device.inl), same parser state
 // between them; see there for the grid batch's table protocol (tagged entries, atomic-max commit, min / max patch).
+//
+// What is new here is how a grid batch gets its candidates' bytes.  The chain  table -> candidate address -> memory -> compare ->
+// walk -> table patch -> next batch's table read  has a memory round trip in it, and nothing to do meanwhile now that the
+// writer is gone.  So the batches run as a pipeline of three stages (batch k-1, k, k+1), each with its window P, its hash /
+// entry, and a PEEK: at the top of batch k -- the table is exact then: batch k-1 is patched, batch k not yet committed --
+// every lane of batch k+1 reads its slot (a plain read) and requests the 20 bytes at that entry's position.  When batch k+1
+// commits, one iteration later, the entry it displaces is either the peeked one (bytes already here), or a lane of batch k that
+// the parser executed, or an earlier lane of batch k+1 itself -- and those two have their windows in registers (prev.P,
+// cur.P): one ds_bpermute round each.  Nothing waits for memory except a cold start (block head, after a generic batch or a
+// long match).  Windows are requested two batches ahead into the stage batch k-1 no longer needs; the three stages rotate
+// by unrolling (grid(S2,S0,S1), grid(S0,S1,S2), grid(S1,S2,S0)), not by copies.
+#if defined(PLZ4_EMU)
+#define SHFLF(x, f, l) ((x)[(l) & 63].f)
+unsigned long long plz4_emu_cnt[8]; unsigned long long plz4_emu_deep[4];               // test diagnostics: grid batches, cold starts, lanes reloaded from memory, twin repairs
+#define EMU_CNT(i, v) (plz4_emu_cnt[(i)] += (unsigned long long)(v))
+#else
+#define SHFLF(x, f, l) plz4_bpermute((x)[0].f, (l))
+#define EMU_CNT(i, v) do {} while (0)
+#endif
+struct GStage { Win20 P; Win20 C; uint32_t h, ent, pk; };     // window, candidate window, slot, own entry, peeked entry
+// diagnostics build (-DPLZ4_STATS, scripts/stats_probe_l1.py): cycle stamps around the sections of a grid batch, each section
+// closed by an explicit wait so that its stamp owns the latency it exposes
+#if defined(PLZ4_STATS) && !defined(PLZ4_EMU)
+#define STAT_WAIT_VM()   __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define STAT_WAIT_LGKM() __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+#define STAT_WAIT_VM()   do {} while (0)
+#define STAT_WAIT_LGKM() do {} while (0)
+#endif
+enum { P_BATCH = 0, P_CYC_MEM, P_CYC_LDS, P_CYC_REFRESH, P_CYC_CMP, P_CYC_WALK, P_CYC_TAIL, P_REPAIR, P_PRIME, P_GENERIC, P_CYC_TOTAL, P_BLOCKS, P_SEQ, P_CYC_GEN, P_CYC_NH, P_CYC_HOP, P_CYC_E, P_CYC_SLOW, P_HOPS };
+
 template <bool U16>
 DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab, uint64_t* __restrict__ seq, int* lastAnchor)
 {
@@ -94,226 +125,424 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
     const int lastProbe  = n - kMfLimit + 1;      // mflimitPlusOne (lz4.c:963)
     const int matchLimit = n - kLastLiterals;     // lz4.c:964
     int nseq = 0, anchor = 0;
+    STAT_DECL;
+    const unsigned long long tBlock0 = STAT_NOW(); (void)tBlock0;
 
     if (n >= kMinLength) {
         int  insPos  = 0; bool hasIns = true;      // pending table insert ("First Byte" lz4.c:1005-1010; ip-2 lz4.c:1236-1242)
         int  rePos   = 0; bool hasRe  = false;     // pending immediate re-test at ip after a match (lz4.c:1255-1294)
         int  sBase   = 1; int sIter = 0;           // search started at sBase; next un-probed probe number
         int  width   = 16;                         // generic batches: 16 lanes first, 64 when a search drags on
-        LV(Win20, Pn); int prefBase = -1;          // next window's bytes, requested one batch ahead
-        LV(Win20, Pc);
-        LANES({ for (int k = 0; k < 5; ++k) Pn[I_].w[k] = 0; Pc[I_] = Pn[I_]; })
+        // the pipeline's three stages; which one is batch k-1 / k / k+1 rotates with the unrolled loop below
+        LV(GStage, S0); LV(GStage, S1); LV(GStage, S2);
+        LANES({ for (int k = 0; k < 5; ++k) { S0[I_].P.w[k] = 0; S0[I_].C.w[k] = 0; } S0[I_].h = 0; S0[I_].ent = 0; S0[I_].pk = 0; S1[I_] = S0[I_]; S2[I_] = S0[I_]; })
+        enum { kGridNext = 0, kGridDone = 1, kGridGeneric = 2, kGridStop = 3 };
+
+        // One batch of the steady state.  On entry: cur.P = the window of `base`, cur.h / ent = its slot and entry, cur.pk = what the
+        // slot held when the table was last exact before this batch, cur.C = the window at that entry's position (requested a
+        // batch ago), next.P = the window of base + 64 (requested a batch ago), prev.P = the window of base - 64 when the batch
+        // before was a grid batch.  Every load below is unconditional: the number of memory operations in flight at any point of
+        // the loop is fixed, so waiting for one of them never means waiting for a younger one.
+        auto grid = [&](LVREF(GStage, prev), LVREF(GStage, cur), LVREF(GStage, next), const int base) -> int {
+            if (sIter > 64) return kGridStop;
+            const int probeStart = hasRe ? rePos : sBase + sIter;
+            const int firstPos   = hasIns ? insPos : probeStart;
+            if ((firstPos & ~63) != base || base + 224 > n) return kGridStop;
+            uint32_t* T = (uint32_t*)tab;
+            LV(bool, act); LV(uint32_t, r); LV(uint32_t, rent); LV(bool, hit); LV(int, fwd); LV(int, eLane); LV(bool, cand);
+            EMU_CNT(0, 1); STAT(P_BATCH, 1);
+            const unsigned long long ts0 = STAT_NOW(); (void)ts0;
+            STAT_WAIT_VM();
+            const unsigned long long ts1 = STAT_NOW(); (void)ts1;
+            STAT(P_CYC_MEM, ts1 - ts0);
+            // ---- 1. peek for batch k+1 on the exact table, then this batch's table exchange
+            LANES({
+                next[I_].h   = seq_hash<false>(win20_seq(next[I_].P));
+                next[I_].ent = ((uint32_t)(base + 64 + LANE) << sh) | (seq_tag(next[I_].P.w[0]) & tagMask);
+                next[I_].pk  = T[next[I_].h];
+            })
+            LDS_ORDER();
+            LANES({
+                const int q = base + LANE;
+                const int isIns = hasIns && q == insPos;
+                act[I_] = isIns || q >= probeStart;
+                hit[I_] = false; fwd[I_] = 0; r[I_] = 0; rent[I_] = 0; cand[I_] = false;
+                if (act[I_]) {
+                    rent[I_] = lds_max_rtn(&T[cur[I_].h], cur[I_].ent);
+                    r[I_]    = rent[I_] >> sh;
+                    cand[I_] = !isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q && ((rent[I_] ^ cur[I_].ent) & tagMask) == 0;
+                }
+            })
+            // LDS atomics on one slot are expected to resolve in ascending lane order (then r is the nearest earlier twin or the
+            // pre-batch value): any other order shows up as r >= q somewhere.  And an entry that is neither the peeked one nor a
+            // position of this batch or the one before cannot be (nothing else touched the table since the peek).  Either way:
+            // the commits are taken back and the generic batch takes over.
+            STAT_WAIT_LGKM();
+            const unsigned long long ts2 = STAT_NOW(); (void)ts2;
+            STAT(P_CYC_LDS, ts2 - ts1);
+            const uint64_t misorder = BALLOT(act[I_] && (r[I_] >= (uint32_t)(base + LANE) ||
+                                                         (cand[I_] && rent[I_] != cur[I_].pk && r[I_] + 64u < (uint32_t)base)));
+            if (misorder) {
+                EMU_CNT(2, 1);
+                LANES({ if (act[I_]) lds_min(&T[cur[I_].h], rent[I_]); })  // min over a slot's group == its pre-batch value
+                LDS_FENCE();
+                return kGridGeneric;
+            }
+            // ---- 2. candidates and their windows.  The entry a lane displaced (rent) is the slot's content under the assumption
+            // that every earlier lane of this batch was executed.  Its window: the peeked one when the entry is the peeked entry,
+            // else the entry is a position of this batch or of the batch before (nothing else touched the table since the peek)
+            // and the window is in registers there: one ds_bpermute round per source, no branch.
+            LV(bool, pb);                                  // a lane that can be a probe (active, not the pending insert)
+            LV(Win20, W0);                                 // window of rent's position
+            LANES({ pb[I_] = act[I_] && !(hasIns && base + LANE == insPos); })
+            auto gather = [&](LVREF(uint32_t, ceV), LVREF(Win20, W)) {
+                LANES({
+                    const int t = (int)(ceV[I_] >> sh) - base;               // (& 63: the lane in either batch)
+                    const bool same = ceV[I_] == cur[I_].pk;
+                    for (int k = 0; k < 5; ++k) {
+                        const uint32_t a = SHFLF(cur, P.w[k], t), b = SHFLF(prev, P.w[k], t);
+                        W[I_].w[k] = same ? cur[I_].C.w[k] : (t >= 0 ? a : b);
+                    }
+                })
+            };
+            auto compare = [&](LVREF(uint32_t, ceV), LVREF(Win20, W), LVREF(bool, hitV), LVREF(int, fwdV)) {
+                LANES({
+                    const uint32_t q = (uint32_t)(base + LANE), cp = ceV[I_] >> sh;
+                    const bool ok = pb[I_] && cp < q && cp + kMaxDist >= q && ((ceV[I_] ^ cur[I_].ent) & tagMask) == 0;
+                    hitV[I_] = ok && W[I_].w[0] == cur[I_].P.w[0];
+                    fwdV[I_] = hitV[I_] ? win20_fwd(cur[I_].P, W[I_]) : 0;
+                })
+            };
+            gather(rent, W0);
+            STAT_WAIT_LGKM();
+            const unsigned long long ts3 = STAT_NOW(); (void)ts3;
+            STAT(P_CYC_REFRESH, ts3 - ts2);
+            compare(rent, W0, hit, fwd);
+            LANES({ eLane[I_] = LANE + kMinMatch + fwd[I_]; })    // lane index just past a match that starts here
+            // ---- 3. requests for the batches to come: the peeked candidates of batch k+1 (every lane loads: its candidate, or
+            // its own position when it has none), the window of batch k+2 into registers batch k-1 is done with (its C: its P
+            // still serves this batch's chains; they change places at the end)
+            LANES({
+                const uint32_t q1 = (uint32_t)(base + 64 + LANE), pr = next[I_].pk >> sh;
+                const bool pc = pr < q1 && pr + kMaxDist >= q1 && ((next[I_].pk ^ next[I_].ent) & tagMask) == 0;
+                next[I_].C = load_win20(src, (int)(pc ? pr : q1));
+                prev[I_].C = load_win20(src, base + 128 + LANE);
+            })
+
+            const uint64_t hits0  = BALLOT(hit[I_]);
+            const unsigned long long ts4 = STAT_NOW(); (void)ts4;
+            STAT(P_CYC_CMP, ts4 - ts3);
+            const uint64_t twins0 = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);   // earlier twin inside this batch
+            const uint64_t anyTwins = twins0;
+            const uint64_t special0 = hits0 & BALLOT(fwd[I_] == 16);           // longer than the speculative window: the hop needs its end
+            const int  cur0 = probeStart - base;                  // first probe lane (>= 64: none in this batch)
+            const bool re0  = hasRe;
+            const uint64_t insBit0 = hasIns ? (1ull << (insPos - base)) : 0;
+            int lim0 = sBase + 65 - base; if (lim0 > 63) lim0 = 63;   // probe number <= 65 keeps the stride at 1
+
+            uint64_t mm = 0;           // executed match lanes
+            int      eL = 0;           // end lane of the last executed match
+            uint64_t E = 0;            // executed lanes (probes + inserts)
+            int      Send = 0;
+            bool     finished = false;
+            // ---- 4. the walk, in straight passes: scalar hop over the recorded matches, the executed lanes derived per lane
+            // (walk_pass).  Then: does a probe's candidate lie in a lane of this batch the parser did not execute?  Such lanes
+            // -- all of them at once -- follow the chain of displaced entries down to the first executed lane or to an entry
+            // from before the batch (resolve), fetch that window from the registers and compare again; the walk is redone only
+            // if a probe's hit or length changed, and the result stands once a resolve under the final executed set changes no
+            // probe's candidate (the sequential parse is the one consistent assignment: a lane depends on lower lanes only).
+            // A match longer than the speculative window under the hop, a chain that leaves the registers, or three rounds
+            // without agreement send the batch through the general loop below instead.
+            uint64_t probes = 0;
+            auto walk_pass = [&](const uint64_t hitsM, LVREF(int, eV)) {
+                LV(int, nextHit);      // first recorded match at or after the end of the match that starts here (64: none)
+                LANES({
+                    const uint64_t ah = (eV[I_] < 64) ? (hitsM >> eV[I_]) : 0;
+                    nextHit[I_] = ah ? eV[I_] + ctz64(ah) : 64;
+                })
+                mm = 0; eL = 0;
+                int w = 64;
+                if (cur0 < 64) { const uint64_t hm = hitsM & (~0ull << cur0); if (hm) w = ctz64(hm); }
+                if (w > lim0) w = 64;                                  // (the stride limit concerns the first match only)
+                const unsigned long long tw1 = STAT_NOW(); (void)tw1;
+                if (w < 64) {
+                    const uint64_t low = (w == 0 ? 1ull : 0ull);
+                    do {
+                        for (int u = 0; u < 4; ++u) {
+                            const int n1 = RL(nextHit, w & 63);
+                            mm |= 1ull << (w & 63);
+                            w = (w < 64) ? n1 : 64;
+                        }
+                        STAT(P_HOPS, 4);
+                    } while (w < 64);
+                    mm = (mm & ~1ull) | low;
+                    eL = RL(eV, 63 - __builtin_clzll(mm));
+                }
+                const unsigned long long tw2 = STAT_NOW(); (void)tw2;
+                STAT(P_CYC_HOP, tw2 - tw1);
+                Send = mm ? 64 : min_(64, lim0 + 1);
+                const uint64_t mmL = mm; const int SendL = Send;
+                LV(int, stA);
+                LANES({ stA[I_] = ((mmL >> LANE) & 1) ? eV[I_] : 0; })
+                SCAN_MAX_EXCL(stA);
+                const uint64_t hasPm = BALLOT(stA[I_] > 0);
+                LANES({ stA[I_] = stA[I_] > 0 ? stA[I_] : cur0; })                // where probing resumed before me
+                probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
+                E = probes | insBit0 | (hasPm & BALLOT(stA[I_] == LANE + 2));      // + the ip-2 inserts (lz4.c:1236-1242)
+                STAT(P_CYC_E, STAT_NOW() - tw2);
+            };
+            bool slow;
+            walk_pass(hits0, eLane);
+            slow = (mm & special0) != 0;
+            EMU_CNT(4, slow);
+#if defined(PLZ4_EMU) && defined(PLZ4_EMU_TRACE)
+            if (base < 200) { fprintf(stderr, "base %d cur0 %d probes %llx E %llx twins %llx mm %llx slow %d hasIns %d insPos %d\n", base, cur0, (unsigned long long)probes, (unsigned long long)E, (unsigned long long)twins0, (unsigned long long)mm, (int)slow, (int)hasIns, insPos);
+                for (int l = 0; l < 64; ++l) fprintf(stderr, " l%d r%u pk%u hit%d fwd%d |", l, rent[l] >> sh, cur[l].pk >> sh, (int)hit[l], fwd[l]); fprintf(stderr, "\n"); }
+#endif
+            if (!slow && (twins0 & probes)) {
+                const uint64_t EL0 = E;
+                const uint64_t bad = twins0 & probes & BALLOT(!((EL0 >> (((int)r[I_] - base) & 63)) & 1));
+                if (bad) {
+                    EMU_CNT(5, 1);
+#if defined(PLZ4_EMU) && defined(PLZ4_EMU_TRACE)
+                    if (base == 64) { fprintf(stderr, "base 64 bad %llx probes %llx E %llx twins %llx mm %llx\n", (unsigned long long)bad, (unsigned long long)probes, (unsigned long long)E, (unsigned long long)twins0, (unsigned long long)mm);
+                        for (int l = 0; l < 64; ++l) fprintf(stderr, " l%d r%u pk%u hit%d fwd%d |", l, rent[l] >> sh, cur[l].pk >> sh, (int)hit[l], fwd[l]); fprintf(stderr, "\n"); }
+#endif
+                    LV(uint32_t, ce); LV(Win20, W1);
+                    LANES({ ce[I_] = rent[I_]; })
+                    int it = 0;
+                    for (; it < 3 && !slow; ++it) {
+                        // resolve under E: from the commit's answer down the chain of displaced entries
+                        LV(uint32_t, ce2);
+                        LANES({ ce2[I_] = rent[I_]; })
+                        for (;;) {
+                            const uint64_t EL = E;
+                            const uint64_t mv = BALLOT(pb[I_] && (ce2[I_] >> sh) >= (uint32_t)firstPos && !((EL >> (((int)(ce2[I_] >> sh) - base) & 63)) & 1));   // (an entry of [base, firstPos) is older than the batch)
+                            if (!mv) break;
+                            LANES({ const uint32_t nx = SHFL(rent, (int)(ce2[I_] >> sh) - base); if ((mv >> LANE) & 1) ce2[I_] = nx; })
+                        }
+                        if (!(BALLOT(ce2[I_] != ce[I_]) & probes)) break;          // every probe has the candidate the parser saw
+                        LANES({ ce[I_] = ce2[I_]; })
+                        // an entry from before the previous batch that is not the peeked one: its window is not in the registers
+                        if (BALLOT(pb[I_] && ce[I_] != cur[I_].pk && (ce[I_] >> sh) + 64u < (uint32_t)base) & probes) { slow = true; break; }
+                        LV(bool, hitN); LV(int, fwdN);
+                        gather(ce, W1);
+                        compare(ce, W1, hitN, fwdN);
+                        const uint64_t diff = BALLOT(hitN[I_] != hit[I_] || fwdN[I_] != fwd[I_]) & probes;
+                        LANES({ hit[I_] = hitN[I_]; fwd[I_] = fwdN[I_]; eLane[I_] = LANE + kMinMatch + fwdN[I_]; r[I_] = ce[I_] >> sh; })
+                        if (!diff) break;                                          // same walk, same executed set: consistent
+                        EMU_CNT(6, 1);
+                        const uint64_t hitsN = BALLOT(hit[I_]);
+                        walk_pass(hitsN, eLane);
+                        if (mm & hitsN & BALLOT(fwd[I_] == 16)) slow = true;
+                    }
+                    if (it == 3) slow = true;
+                    if (slow) {                                                    // back to the commit's answer for the general loop
+                        EMU_CNT(7, 1);
+                        compare(rent, W0, hit, fwd);
+                        LANES({ eLane[I_] = LANE + kMinMatch + fwd[I_]; r[I_] = rent[I_] >> sh; })
+                    }
+                }
+            }
+            const unsigned long long tw3 = STAT_NOW(); (void)tw3;
+            if (slow) {
+            uint64_t hits = hits0, twins = twins0, specialLeft = special0;
+            uint64_t cwValid = BALLOT(cand[I_]);                       // lanes whose C holds the window of their rent's position
+            mm = 0; eL = 0; E = 0; Send = 0;
+            STAT(P_REPAIR, 1);
+            // ---- 4. scalar hop over the recorded matches only; everything else is derived per lane
+            LV(int, stA);
+            // after a twin repair at lane b the walk is redone from b only: what it did below b does not depend on b
+            uint64_t keep = 0; int resume = -1;
+            for (;;) {
+                LV(int, nextHit);      // first recorded match at or after the end of the match that starts here (64: none)
+                {
+                    const uint64_t hitsL = hits;
+                    LANES({
+                        const uint64_t ah = (eLane[I_] < 64) ? (hitsL >> eLane[I_]) : 0;
+                        nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
+                    })
+                }
+                mm = keep; eL = 0; finished = false;
+                int w = 64;
+                {
+                    const int start = resume >= 0 ? resume : cur0;     // lane b was a probe: the parser is searching there
+                    if (start < 64) { const uint64_t hm = hits & (~0ull << start); if (hm) w = ctz64(hm); }
+                }
+                if (w < 64 && (mm != 0 || w <= lim0)) {               // (the stride limit concerns the first match only)
+                    // Hops come four to a branch.  A hop is: mark the lane, fetch its successor.  Once the walk has ended
+                    // (w == 64) the remaining hops of a group only touch bit 0 of the mask, which no hop but the very
+                    // first can legitimately set.  Matches longer than the speculative window are not known to the hop: it
+                    // walks through them as if they ended there, and the first one it touched is put right afterwards.
+                    for (;;) {
+                        const uint64_t low = (mm & 1) | (w == 0 ? 1ull : 0ull);
+                        do {
+                            for (int u = 0; u < 4; ++u) {
+                                const int n1 = RL(nextHit, w & 63);
+                                mm |= 1ull << (w & 63);
+                                w = (w < 64) ? n1 : 64;
+                            }
+                        } while (w < 64);
+                        mm = (mm & ~1ull) | low;
+                        const uint64_t sp = mm & specialLeft;
+                        if (!sp) break;
+                        const int ws = ctz64(sp);
+                        mm &= (2ull << ws) - 1;                       // what the walk did after it is void
+                        const int p0 = base + ws, c0 = (int)RL(r, ws);
+                        int mc0 = (int)RL(fwd, ws);
+                        if (mc0 == 16) { mc0 += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); WL(fwd, ws, mc0); }
+                        specialLeft &= ~(1ull << ws);
+                        const int e1 = ws + kMinMatch + mc0;
+                        WL(eLane, ws, e1);
+                        if (base + e1 >= lastProbe) { finished = true; break; }   // lz4.c:1233 (only a long match gets there)
+                        const uint64_t hm = (e1 < 64) ? (hits & (~0ull << e1)) : 0;
+                        w = hm ? ctz64(hm) : 64;
+                        if (w >= 64) break;
+                    }
+                }
+                if (mm) eL = RL(eLane, 63 - __builtin_clzll(mm));
+                // ---- 5. which lanes did the sequential parser execute
+                Send = mm ? 64 : min_(64, lim0 + 1);
+                const uint64_t mmL = mm; const int SendL = Send;
+                // end of the last executed match below each lane: ends grow along the walk, so an exclusive
+                // prefix maximum over the match lanes (DPP, no LDS round trip) is that value
+                LANES({ stA[I_] = ((mmL >> LANE) & 1) ? eLane[I_] : 0; })
+                SCAN_MAX_EXCL(stA);
+                const uint64_t hasPm = BALLOT(stA[I_] > 0);
+                LANES({ stA[I_] = stA[I_] > 0 ? stA[I_] : cur0; })                // where probing resumed before me
+                const uint64_t probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
+                E = probes | insBit0 | (hasPm & BALLOT(stA[I_] == LANE + 2));      // + the ip-2 inserts (lz4.c:1236-1242)
+                if (twins & probes) {
+                    // A probe whose candidate is an earlier lane of this batch is only right if that lane was executed.
+                    // Otherwise the sequential parser saw what that lane displaced (or what *it* displaced, ...):
+                    // repair the first such lane in place and redo the (cheap) hop.
+                    const uint64_t EL = E;
+                    const uint64_t bad = twins & probes & BALLOT(!((EL >> (((int)r[I_] - base) & 63)) & 1));
+                    if (bad) {
+                        EMU_CNT(3, 1);
+                        const int b = ctz64(bad);
+                        uint32_t ce = RL(rent, b);                          // entry lane b displaced
+                        int tl = -1;                                        // the lane whose displaced entry `ce` is
+                        for (;;) {
+                            const uint32_t ci = ce >> sh;
+                            if (ci < (uint32_t)firstPos) break;             // a pre-batch entry
+                            const int t = (int)ci - base;
+                            if ((E >> t) & 1) break;                        // an executed lane of this batch
+                            ce = RL(rent, t);                               // a skipped lane: what it displaced
+                            tl = t;
+                        }
+                        const uint32_t cp = ce >> sh, qb = (uint32_t)(base + b);
+                        int nhit = 0, nfwd = 0;
+                        if (cp + kMaxDist >= qb && ((ce ^ RLF(cur, ent, b)) & tagMask) == 0) {
+                            Win20 Pb; for (int k = 0; k < 5; ++k) Pb.w[k] = RLF(cur, P.w[k], b);
+                            Win20 Cn;
+                            if (cp >= (uint32_t)base) { const int t = (int)cp - base; for (int k = 0; k < 5; ++k) Cn.w[k] = RLF(cur, P.w[k], t); }
+                            // a pre-batch entry was displaced by lane tl, and if that lane took it for a candidate (a twin
+                            // usually repeats the very same bytes) its window already holds what is needed: no memory round trip
+                            else if (tl >= 0 && ((cwValid >> tl) & 1)) { for (int k = 0; k < 5; ++k) Cn.w[k] = RLF(W0, w[k], tl); }
+                            else { Cn = load_win20(src, (int)cp); for (int k = 0; k < 5; ++k) Cn.w[k] = UNI(Cn.w[k]); }
+                            if (Cn.w[0] == Pb.w[0]) { nhit = 1; nfwd = win20_fwd(Pb, Cn); }
+                        }
+                        WL(rent, b, ce); WL(r, b, cp); WL(hit, b, nhit != 0); WL(fwd, b, nfwd);
+                        WL(eLane, b, b + kMinMatch + nfwd);
+                        const uint64_t bit = 1ull << b;
+                        hits = nhit ? (hits | bit) : (hits & ~bit);
+                        specialLeft = (nhit && nfwd == 16) ? (specialLeft | bit) : (specialLeft & ~bit);
+                        twins &= ~bit;
+                        cwValid &= ~bit;                                    // lane b's C no longer belongs to its (new) rent
+                        keep = mm & (bit - 1); resume = b;
+                        continue;
+                    }
+                }
+                break;
+            }
+            }
+            // lz4.c:1233: a match that ends at or past the last probe position ends the block.  Decided here, from the
+            // final walk: the pass that finished a long match may have been redone after a twin repair, and the redo
+            // sees that match as an ordinary one.
+            finished = (mm != 0) && (base + eL >= lastProbe);
+            const unsigned long long ts5 = STAT_NOW(); (void)ts5;
+            STAT(P_CYC_WALK, ts5 - ts4); STAT(P_CYC_SLOW, ts5 - tw3);
+
+            // ---- 6. one record per executed match
+            if (mm) {
+                const uint64_t mmL = mm; const int at = nseq;
+                LANES({
+                    if ((mmL >> LANE) & 1)
+                        seq[at + LANE_RANK(mmL)] = seq_pack((uint32_t)(base + LANE), (uint32_t)fwd[I_], (uint32_t)(base + LANE) - r[I_]);
+                })
+                nseq += __builtin_popcountll(mm);
+                anchor = base + eL;
+            }
+            if (finished) return kGridDone;
+
+            // ---- 7. parser state after this batch
+            hasIns = false;
+            if (cur0 < 64) hasRe = false;
+            if (mm) {
+                sBase = base + eL + 1; sIter = 0;
+                if (eL - 2 >= 64) { hasIns = true; insPos = base + eL - 2; }
+                if (eL >= Send) { hasRe = true; rePos = base + eL; }       // its re-test is not executed in this batch
+                else sIter = (base + Send) - sBase;                         // lanes eL..Send-1 missed (eL was the re-test)
+            } else if (cur0 < 64) {
+                if (Send > cur0) sIter = (base + Send) - sBase;             // lanes cur0..Send-1 missed
+                else if (re0) { hasRe = true; rePos = base + cur0; }
+            }
+
+            // ---- 8. patch the table to the sequential result
+            const uint64_t EL2 = E;
+            LANES({ if (act[I_] && !((EL2 >> LANE) & 1)) lds_min(&T[cur[I_].h], rent[I_]); })
+            if (anyTwins) { LDS_ORDER(); LANES({ if ((EL2 >> LANE) & 1) lds_max(&T[cur[I_].h], cur[I_].ent); }) }
+            LDS_ORDER();
+            width = 64;
+            LANES({ prev[I_].P = prev[I_].C; })                            // the window of batch k+2 takes its place
+            STAT(P_CYC_TAIL, STAT_NOW() - ts5);
+            return kGridNext;
+        };
 
         for (;;) {
             // ================================================================ GRID batch
             if (!U16 && sIter <= 64) {
                 const int probeStart = hasRe ? rePos : sBase + sIter;
                 const int firstPos   = hasIns ? insPos : probeStart;
-                const int base       = firstPos & ~63;
-                if (base >= 64 && base + 96 <= n) {
-                    uint32_t* T = (uint32_t*)tab;
-                    LV(int, act); LV(uint32_t, h); LV(uint32_t, r);
-                    LV(uint32_t, ent); LV(uint32_t, rent);           // my table entry / the entry I displaced
-                    LV(int, hit); LV(int, fwd); LV(int, eLane); LV(int, cand); LV(Win20, Cw);
-                    // ---- 1. every lane: its window, the table exchange, the request for its candidate's window
+                int base = firstPos & ~63;
+                if (base >= 64 && base + 224 <= n) {
+                    // prime the pipeline (the table is exact here): windows of this batch and the next, this batch's slots
+                    // peeked, its candidates requested.  The memory round trips of this start are the only ones the grid
+                    // batches ever wait for.
+                    EMU_CNT(1, 1); STAT(P_PRIME, 1);
                     LANES({
-                        const int q = base + LANE;
-                        const int isIns = hasIns && q == insPos;
-                        act[I_] = isIns || q >= probeStart;
-                        hit[I_] = 0; fwd[I_] = 0; r[I_] = 0; h[I_] = 0; ent[I_] = 0; rent[I_] = 0; cand[I_] = 0;
-                        if (base != prefBase) Pn[I_] = load_win20(src, q);
-                        Pc[I_] = Pn[I_];
-                        if (act[I_]) {
-                            h[I_] = seq_hash<false>(win20_seq(Pc[I_]));
-                            const uint32_t tg = seq_tag(Pc[I_].w[0]) & tagMask;
-                            ent[I_]  = ((uint32_t)q << sh) | tg;
-                            rent[I_] = lds_max_rtn(&T[h[I_]], ent[I_]);
-                            r[I_]    = rent[I_] >> sh;
-                            cand[I_] = !isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q && (rent[I_] & tagMask) == tg;
-                            if (cand[I_]) Cw[I_] = load_win20(src, (int)r[I_]);
-                        }
-                        if (base + 160 <= n) Pn[I_] = load_win20(src, q + 64);   // request the next window now, use it next batch
+                        S0[I_].P = load_win20(src, base + LANE);
+                        S1[I_].P = load_win20(src, base + 64 + LANE);
+                        S0[I_].h   = seq_hash<false>(win20_seq(S0[I_].P));
+                        S0[I_].ent = ((uint32_t)(base + LANE) << sh) | (seq_tag(S0[I_].P.w[0]) & tagMask);
+                        S0[I_].pk  = ((const uint32_t*)tab)[S0[I_].h];
+                        const uint32_t q0 = (uint32_t)(base + LANE), pr = S0[I_].pk >> sh;
+                        const bool pc = pr < q0 && pr + kMaxDist >= q0 && ((S0[I_].pk ^ S0[I_].ent) & tagMask) == 0;
+                        S0[I_].C = load_win20(src, (int)(pc ? pr : q0));
                     })
-                    prefBase = (base + 160 <= n) ? base + 64 : -1;
-                    LANES({
-                        if (act[I_] && cand[I_] && Cw[I_].w[0] == Pc[I_].w[0]) {
-                            hit[I_] = 1;
-                            fwd[I_] = win20_fwd(Pc[I_], Cw[I_]);
-                        }
-                        eLane[I_] = LANE + kMinMatch + fwd[I_];     // lane index just past a match that starts here
-                    })
-                    // LDS atomics on one slot are expected to resolve in ascending lane order (then r is the
-                    // nearest earlier twin or the pre-batch value).  Any other order shows up as r >= q somewhere.
-                    const uint64_t misorder = BALLOT(act[I_] && r[I_] >= (uint32_t)(base + LANE));
-                    if (misorder) {
-                        LANES({ if (act[I_]) lds_min(&T[h[I_]], rent[I_]); })  // min over a slot's group == its pre-batch value
-                        LDS_FENCE();
-                        goto generic_batch;
+                    LDS_ORDER();
+                    int rc;
+                    for (;;) {
+                        rc = grid(S2, S0, S1, base); if (rc != kGridNext) break; base += 64;
+                        rc = grid(S0, S1, S2, base); if (rc != kGridNext) break; base += 64;
+                        rc = grid(S1, S2, S0, base); if (rc != kGridNext) break; base += 64;
                     }
-                    {
-                        uint64_t hits  = BALLOT(hit[I_]);
-                        uint64_t twins = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);          // earlier twin inside this batch
-                        uint64_t cwValid = BALLOT(act[I_] && cand[I_]);       // lanes whose Cw holds the window of their rent's position
-                        const uint64_t anyTwins = twins;                                          // (bits of repaired lanes get cleared below)
-                        uint64_t specialLeft = BALLOT(hit[I_] && fwd[I_] == 16);           // longer than the speculative window: the hop needs its end
-                        const int  cur0 = probeStart - base;                  // first probe lane (>= 64: none in this batch)
-                        const bool re0  = hasRe;
-                        const uint64_t insBit0 = hasIns ? (1ull << (insPos - base)) : 0;
-                        int lim0 = sBase + 65 - base; if (lim0 > 63) lim0 = 63;   // probe number <= 65 keeps the stride at 1
-
-                        // ---- 2. scalar hop over the recorded matches only; everything else is derived per lane
-                        uint64_t mm = 0;           // executed match lanes
-                        int      eL = 0;           // end lane of the last executed match
-                        uint64_t E = 0;            // executed lanes (probes + inserts)
-                        int      Send = 0;
-                        bool     finished = false;
-                        LV(int, stA);
-                        // after a twin repair at lane b the walk is redone from b only: what it did below b does not depend on b
-                        uint64_t keep = 0; int resume = -1;
-                        for (;;) {
-                            LV(int, nextHit);      // first recorded match at or after the end of the match that starts here (64: none)
-                            {
-                                const uint64_t hitsL = hits;
-                                LANES({
-                                    const uint64_t ah = (eLane[I_] < 64) ? (hitsL >> eLane[I_]) : 0;
-                                    nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
-                                })
-                            }
-                            mm = keep; eL = 0; finished = false;
-                            int w = 64;
-                            {
-                                const int start = resume >= 0 ? resume : cur0;     // lane b was a probe: the parser is searching there
-                                if (start < 64) { const uint64_t hm = hits & (~0ull << start); if (hm) w = ctz64(hm); }
-                            }
-                            if (w < 64 && (mm != 0 || w <= lim0)) {               // (the stride limit concerns the first match only)
-                                // Hops come four to a branch.  A hop is: mark the lane, fetch its successor.  Once the walk has ended
-                                // (w == 64) the remaining hops of a group only touch bit 0 of the mask, which no hop but the very
-                                // first can legitimately set.  Matches longer than the speculative window are not known to the hop: it
-                                // walks through them as if they ended there, and the first one it touched is put right afterwards.
-                                for (;;) {
-                                    const uint64_t low = (mm & 1) | (w == 0 ? 1ull : 0ull);
-                                    do {
-                                        for (int u = 0; u < 4; ++u) {
-                                            const int n1 = RL(nextHit, w & 63);
-                                            mm |= 1ull << (w & 63);
-                                            w = (w < 64) ? n1 : 64;
-                                        }
-                                    } while (w < 64);
-                                    mm = (mm & ~1ull) | low;
-                                    const uint64_t sp = mm & specialLeft;
-                                    if (!sp) break;
-                                    const int ws = ctz64(sp);
-                                    mm &= (2ull << ws) - 1;                       // what the walk did after it is void
-                                    const int p0 = base + ws, c0 = (int)RL(r, ws);
-                                    int mc0 = (int)RL(fwd, ws);
-                                    if (mc0 == 16) { mc0 += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); WL(fwd, ws, mc0); }
-                                    specialLeft &= ~(1ull << ws);
-                                    const int e1 = ws + kMinMatch + mc0;
-                                    WL(eLane, ws, e1);
-                                    if (base + e1 >= lastProbe) { finished = true; break; }   // lz4.c:1233 (only a long match gets there)
-                                    const uint64_t hm = (e1 < 64) ? (hits & (~0ull << e1)) : 0;
-                                    w = hm ? ctz64(hm) : 64;
-                                    if (w >= 64) break;
-                                }
-                            }
-                            if (mm) eL = RL(eLane, 63 - __builtin_clzll(mm));
-                            // ---- 3. which lanes did the sequential parser execute
-                            Send = mm ? 64 : min_(64, lim0 + 1);
-                            const uint64_t mmL = mm; const int SendL = Send;
-                            // end of the last executed match below each lane: ends grow along the walk, so an exclusive
-                            // prefix maximum over the match lanes (DPP, no LDS round trip) is that value
-                            LANES({ stA[I_] = ((mmL >> LANE) & 1) ? eLane[I_] : 0; })
-                            SCAN_MAX_EXCL(stA);
-                            const uint64_t hasPm = BALLOT(stA[I_] > 0);
-                            LANES({ stA[I_] = stA[I_] > 0 ? stA[I_] : cur0; })                // where probing resumed before me
-                            const uint64_t probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
-                            E = probes | insBit0 | (hasPm & BALLOT(stA[I_] == LANE + 2));      // + the ip-2 inserts (lz4.c:1236-1242)
-                            if (twins & probes) {
-                                // A probe whose candidate is an earlier lane of this batch is only right if that lane was executed.
-                                // Otherwise the sequential parser saw what that lane displaced (or what *it* displaced, ...):
-                                // repair the first such lane in place and redo the (cheap) hop.
-                                const uint64_t EL = E;
-                                const uint64_t bad = twins & probes & BALLOT(!((EL >> (((int)r[I_] - base) & 63)) & 1));
-                                if (bad) {
-                                    const int b = ctz64(bad);
-                                    uint32_t ce = RL(rent, b);                          // entry lane b displaced
-                                    int tl = -1;                                        // the lane whose displaced entry `ce` is
-                                    for (;;) {
-                                        const uint32_t ci = ce >> sh;
-                                        if (ci < (uint32_t)firstPos) break;             // a pre-batch entry
-                                        const int t = (int)ci - base;
-                                        if ((E >> t) & 1) break;                        // an executed lane of this batch
-                                        ce = RL(rent, t);                               // a skipped lane: what it displaced
-                                        tl = t;
-                                    }
-                                    const uint32_t cp = ce >> sh, qb = (uint32_t)(base + b);
-                                    int nhit = 0, nfwd = 0;
-                                    if (cp + kMaxDist >= qb && (ce & tagMask) == (RL(ent, b) & tagMask)) {
-                                        Win20 Pb; for (int k = 0; k < 5; ++k) Pb.w[k] = RLF(Pc, w[k], b);
-                                        Win20 Cn;
-                                        if (cp >= (uint32_t)base) { const int t = (int)cp - base; for (int k = 0; k < 5; ++k) Cn.w[k] = RLF(Pc, w[k], t); }
-                                        // a pre-batch entry was displaced by lane tl, and if that lane took it for a candidate (a twin
-                                        // usually repeats the very same bytes) its window already holds what is needed: no memory round trip
-                                        else if (tl >= 0 && ((cwValid >> tl) & 1)) { for (int k = 0; k < 5; ++k) Cn.w[k] = RLF(Cw, w[k], tl); }
-                                        else { Cn = load_win20(src, (int)cp); for (int k = 0; k < 5; ++k) Cn.w[k] = UNI(Cn.w[k]); }
-                                        if (Cn.w[0] == Pb.w[0]) { nhit = 1; nfwd = win20_fwd(Pb, Cn); }
-                                    }
-                                    WL(rent, b, ce); WL(r, b, cp); WL(hit, b, nhit); WL(fwd, b, nfwd);
-                                    WL(eLane, b, b + kMinMatch + nfwd);
-                                    const uint64_t bit = 1ull << b;
-                                    hits = nhit ? (hits | bit) : (hits & ~bit);
-                                    specialLeft = (nhit && nfwd == 16) ? (specialLeft | bit) : (specialLeft & ~bit);
-                                    twins &= ~bit;
-                                    cwValid &= ~bit;                                    // lane b's Cw no longer belongs to its (new) rent
-                                    keep = mm & (bit - 1); resume = b;
-                                    continue;
-                                }
-                            }
-                            break;
+                    if (rc == kGridDone) break;
+                    if (rc == kGridStop) {
+                        // the next batch is not the consecutive one (a long match, a search past 64 misses, the block's end):
+                        // start over if it is still a grid batch, else fall through to the generic one
+                        if (sIter <= 64) {
+                            const int ps = hasRe ? rePos : sBase + sIter;
+                            const int nb = (hasIns ? insPos : ps) & ~63;
+                            if (nb >= 64 && nb + 224 <= n) continue;
                         }
-                        // lz4.c:1233: a match that ends at or past the last probe position ends the block.  Decided here, from the
-                        // final walk: the pass that finished a long match may have been redone after a twin repair, and the redo
-                        // sees that match as an ordinary one.
-                        finished = (mm != 0) && (base + eL >= lastProbe);
-
-                        // ---- 4. one record per executed match
-                        if (mm) {
-                            const uint64_t mmL = mm; const int at = nseq;
-                            LANES({
-                                if ((mmL >> LANE) & 1)
-                                    seq[at + LANE_RANK(mmL)] = seq_pack((uint32_t)(base + LANE), (uint32_t)fwd[I_], (uint32_t)(base + LANE) - r[I_]);
-                            })
-                            nseq += __builtin_popcountll(mm);
-                            anchor = base + eL;
-                        }
-                        if (finished) break;
-
-                        // ---- 5. parser state after this batch
-                        hasIns = false;
-                        if (cur0 < 64) hasRe = false;
-                        if (mm) {
-                            sBase = base + eL + 1; sIter = 0;
-                            if (eL - 2 >= 64) { hasIns = true; insPos = base + eL - 2; }
-                            if (eL >= Send) { hasRe = true; rePos = base + eL; }       // its re-test is not executed in this batch
-                            else sIter = (base + Send) - sBase;                         // lanes eL..Send-1 missed (eL was the re-test)
-                        } else if (cur0 < 64) {
-                            if (Send > cur0) sIter = (base + Send) - sBase;             // lanes cur0..Send-1 missed
-                            else if (re0) { hasRe = true; rePos = base + cur0; }
-                        }
-
-                        // ---- 6. patch the table to the sequential result
-                        const uint64_t EL2 = E;
-                        LANES({ if (act[I_] && !((EL2 >> LANE) & 1)) lds_min(&T[h[I_]], rent[I_]); })
-                        if (anyTwins) { LDS_ORDER(); LANES({ if ((EL2 >> LANE) & 1) lds_max(&T[h[I_]], ent[I_]); }) }
-                        LDS_ORDER();
-                        width = 64;
-                        continue;
                     }
                 }
             }
-generic_batch:
             // ================================================================ GENERIC batch: one lane per probe of the search loop
             {
+            STAT(P_GENERIC, 1);
             const int pre = (hasIns ? 1 : 0) + (hasRe ? 1 : 0);
             LV(int, q); LV(uint32_t, h); LV(uint32_t, old); LV(uint32_t, rb); LV(uint32_t, lo4);
             LV(uint32_t, ent); LV(uint32_t, oldE);
@@ -401,6 +630,8 @@ generic_batch:
         }
     }
     *lastAnchor = anchor;
+    STAT(P_CYC_TOTAL, STAT_NOW() - tBlock0); STAT(P_BLOCKS, 1); STAT(P_SEQ, nseq);
+    STAT_FLUSH();
     return nseq;
 }
 
