@@ -37,7 +37,8 @@ enum : int {
 // per-block results of the parse / scan stages
 struct SeqInfo { int32_t nseq; int32_t lastAnchor; int32_t total; int32_t stored; };
 
-// entries a block of n bytes can need: every sequence consumes at least MINMATCH input bytes
+// entries a block of n bytes can need: every sequence consumes at least MINMATCH input bytes.  The parser's array has one more
+// (a dump entry at index seq_capacity(n)).
 DEV int seq_capacity(int n) { return n / kMinMatch + 2; }
 static inline int seq_capacity_host(int n) { return n / 4 + 2; }
 
@@ -46,6 +47,8 @@ DEV uint32_t seq_pos(uint64_t r) { return (uint32_t)r & 0x3FFFFFu; }
 DEV uint32_t seq_fwd(uint64_t r) { return (uint32_t)(r >> 22) & 0x3FFFFFu; }
 DEV uint32_t seq_off(uint64_t r) { return (uint32_t)(r >> 44) & 0xFFFFu; }
 
+// ((1 << width) - 1) << offset, width and offset below 64 (s_bfm_b64)
+#define BFM64(width, offset) ((((uint64_t)1 << ((width) & 63)) - 1ull) << ((offset) & 63))
 #if defined(PLZ4_EMU)
 #define LANE_RANK(mask) (__builtin_popcountll((mask) & ((1ull << LANE) - 1ull)))
 #else
@@ -63,15 +66,17 @@ DEV Win20 load_win20(const uint8_t* src, int x)
     w.w[4] = ld32u(src + x + 16);
     return w;
 }
-// equal bytes of [x+4, x+20) in two windows: 0..16
+// equal bytes of [x+4, x+20) in two windows: 0..16.  Arithmetic only: on this machine a divergent `if` -- the compiler's
+// s_and_saveexec + s_cbranch_execz skeleton, taken or not -- costs about 45 cycles (scripts/micro/execz.hip), a select 4.
+DEV uint32_t eq_bytes(uint32_t x)                 // leading equal bytes of a dword pair from their XOR: 0..4
+{
+    return (x ? (uint32_t)__builtin_ctz(x) : 32u) >> 3;                   // (v_ffbl_b32 + v_min_u32 32: no branch)
+}
 DEV int win20_fwd(const Win20& p, const Win20& c)
 {
-    const uint32_t x1 = p.w[1] ^ c.w[1], x2 = p.w[2] ^ c.w[2], x3 = p.w[3] ^ c.w[3], x4 = p.w[4] ^ c.w[4];
-    int n = x4 ? 12 + (__builtin_ctz(x4) >> 3) : 16;
-    n = x3 ? 8 + (__builtin_ctz(x3) >> 3) : n;
-    n = x2 ? 4 + (__builtin_ctz(x2) >> 3) : n;
-    n = x1 ? (__builtin_ctz(x1) >> 3) : n;
-    return n;
+    const uint32_t b1 = eq_bytes(p.w[1] ^ c.w[1]), b2 = eq_bytes(p.w[2] ^ c.w[2]), b3 = eq_bytes(p.w[3] ^ c.w[3]), b4 = eq_bytes(p.w[4] ^ c.w[4]);
+    const uint32_t m1 = (b1 == 4u), m2 = m1 & (b2 == 4u), m3 = m2 & (b3 == 4u);
+    return (int)(b1 + (m1 ? b2 : 0u) + (m2 ? b3 : 0u) + (m3 ? b4 : 0u));
 }
 
 // ------------------------------------------------------------------------------------------ PARSE
@@ -124,6 +129,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
 
     const int lastProbe  = n - kMfLimit + 1;      // mflimitPlusOne (lz4.c:963)
     const int matchLimit = n - kLastLiterals;     // lz4.c:964
+    const int seqDump    = seq_capacity(n);       // one entry behind the records: where lanes without a record store
     int nseq = 0, anchor = 0;
     STAT_DECL;
     const unsigned long long tBlock0 = STAT_NOW(); (void)tBlock0;
@@ -138,238 +144,97 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
         LANES({ for (int k = 0; k < 5; ++k) { S0[I_].P.w[k] = 0; S0[I_].C.w[k] = 0; } S0[I_].h = 0; S0[I_].ent = 0; S0[I_].pk = 0; S1[I_] = S0[I_]; S2[I_] = S0[I_]; })
         enum { kGridNext = 0, kGridDone = 1, kGridGeneric = 2, kGridStop = 3 };
 
-        // One batch of the steady state.  On entry: cur.P = the window of `base`, cur.h / ent = its slot and entry, cur.pk = what the
-        // slot held when the table was last exact before this batch, cur.C = the window at that entry's position (requested a
-        // batch ago), next.P = the window of base + 64 (requested a batch ago), prev.P = the window of base - 64 when the batch
-        // before was a grid batch.  Every load below is unconditional: the number of memory operations in flight at any point of
-        // the loop is fixed, so waiting for one of them never means waiting for a younger one.
+        // One batch of the steady state: WALK, then COMMIT, then VERIFY.  On entry: cur.P = the window of `base`, cur.h / ent = its
+        // slot and entry, cur.pk = what the slot held at the top of the previous batch, cur.C = the window at that entry's position
+        // (requested a batch ago), next.P = the window of base + 64 (requested a batch ago), prev.P = the window of base - 64
+        // when the batch before was a grid batch.
+        //   walk    every lane is compared with its peeked candidate; a scalar hop over the hits plays the parser from the
+        //           first probe lane on and the executed lanes (probes + the ip-2 inserts) follow per lane.  No table traffic.
+        //   commit  ONLY the executed lanes exchange their entry with the table (one atomic max each, lanes of one slot in lane
+        //           order): the table never holds a position the parser did not insert, so there is nothing to patch
+        //           afterwards, and what a lane gets back is what the sequential parser read there -- the slot's content from
+        //           before the batch, or the nearest executed lane below it.
+        //   verify  a probe that got back the entry it had assumed is done.  One that did not (its slot was taken by an executed
+        //           lane of this batch or of the one before, after the peek) takes the returned entry as its candidate -- that
+        //           window is in the registers of this stage or the previous one, a ds_bpermute away -- and is compared again; if
+        //           neither hit nor length of any probe changed, the walk stands (only offsets moved).  Else the commits are
+        //           taken back (min with what each displaced restores the slots) and the round is repeated on the new
+        //           candidates.  The sequential parse is the one consistent outcome (a lane depends on lower lanes only), so the
+        //           first round that verifies is it.  Three rounds without agreement, or an entry whose window is not in the
+        //           registers: commits taken back, the generic batch takes over.
+        // The loads are unconditional, so the number of memory operations in flight at any point of the loop is fixed.
         auto grid = [&](LVREF(GStage, prev), LVREF(GStage, cur), LVREF(GStage, next), const int base) -> int {
-            if (sIter > 64) return kGridStop;
             const int probeStart = hasRe ? rePos : sBase + sIter;
             const int firstPos   = hasIns ? insPos : probeStart;
-            if ((firstPos & ~63) != base || base + 224 > n) return kGridStop;
+            if ((sIter > 64) | ((firstPos & ~63) != base) | (base + 224 > n)) return kGridStop;
             uint32_t* T = (uint32_t*)tab;
-            LV(bool, act); LV(uint32_t, r); LV(uint32_t, rent); LV(bool, hit); LV(int, fwd); LV(int, eLane); LV(bool, cand);
             EMU_CNT(0, 1); STAT(P_BATCH, 1);
             const unsigned long long ts0 = STAT_NOW(); (void)ts0;
             STAT_WAIT_VM();
             const unsigned long long ts1 = STAT_NOW(); (void)ts1;
             STAT(P_CYC_MEM, ts1 - ts0);
-            // ---- 1. peek for batch k+1 on the exact table, then this batch's table exchange
+            // ---- 1. peek for batch k+1 (the table holds exactly the parser's inserts up to this batch)
             LANES({
                 next[I_].h   = seq_hash<false>(win20_seq(next[I_].P));
                 next[I_].ent = ((uint32_t)(base + 64 + LANE) << sh) | (seq_tag(next[I_].P.w[0]) & tagMask);
                 next[I_].pk  = T[next[I_].h];
             })
             LDS_ORDER();
-            LANES({
-                const int q = base + LANE;
-                const int isIns = hasIns && q == insPos;
-                act[I_] = isIns || q >= probeStart;
-                hit[I_] = false; fwd[I_] = 0; r[I_] = 0; rent[I_] = 0; cand[I_] = false;
-                if (act[I_]) {
-                    rent[I_] = lds_max_rtn(&T[cur[I_].h], cur[I_].ent);
-                    r[I_]    = rent[I_] >> sh;
-                    cand[I_] = !isIns && r[I_] < (uint32_t)q && r[I_] + kMaxDist >= (uint32_t)q && ((rent[I_] ^ cur[I_].ent) & tagMask) == 0;
-                }
-            })
-            // LDS atomics on one slot are expected to resolve in ascending lane order (then r is the nearest earlier twin or the
-            // pre-batch value): any other order shows up as r >= q somewhere.  And an entry that is neither the peeked one nor a
-            // position of this batch or the one before cannot be (nothing else touched the table since the peek).  Either way:
-            // the commits are taken back and the generic batch takes over.
+            // ---- 2. this batch against its peeked candidates
+            LV(uint32_t, ce); LV(uint32_t, rent); LV(bool, hit); LV(int, fwd); LV(int, eLane);
+            auto compare = [&](LVREF(Win20, W), LVREF(bool, hitV), LVREF(int, fwdV)) {
+                LANES({
+                    const uint32_t q = (uint32_t)(base + LANE), cp = ce[I_] >> sh;
+                    const bool ok = (cp < q) & (cp + kMaxDist >= q) & (((ce[I_] ^ cur[I_].ent) & tagMask) == 0) & (W[I_].w[0] == cur[I_].P.w[0]);
+                    const int f = win20_fwd(cur[I_].P, W[I_]);
+                    hitV[I_] = ok;
+                    fwdV[I_] = ok ? f : 0;
+                })
+            };
+            LV(Win20, W);
+            LANES({ ce[I_] = cur[I_].pk; rent[I_] = 0; W[I_] = cur[I_].C; })
+            compare(W, hit, fwd);
+            LANES({ eLane[I_] = LANE + kMinMatch + fwd[I_]; })    // lane index just past a match that starts here
             STAT_WAIT_LGKM();
             const unsigned long long ts2 = STAT_NOW(); (void)ts2;
             STAT(P_CYC_LDS, ts2 - ts1);
-            const uint64_t misorder = BALLOT(act[I_] && (r[I_] >= (uint32_t)(base + LANE) ||
-                                                         (cand[I_] && rent[I_] != cur[I_].pk && r[I_] + 64u < (uint32_t)base)));
-            if (misorder) {
-                EMU_CNT(2, 1);
-                LANES({ if (act[I_]) lds_min(&T[cur[I_].h], rent[I_]); })  // min over a slot's group == its pre-batch value
-                LDS_FENCE();
-                return kGridGeneric;
-            }
-            // ---- 2. candidates and their windows.  The entry a lane displaced (rent) is the slot's content under the assumption
-            // that every earlier lane of this batch was executed.  Its window: the peeked one when the entry is the peeked entry,
-            // else the entry is a position of this batch or of the batch before (nothing else touched the table since the peek)
-            // and the window is in registers there: one ds_bpermute round per source, no branch.
-            LV(bool, pb);                                  // a lane that can be a probe (active, not the pending insert)
-            LV(Win20, W0);                                 // window of rent's position
-            LANES({ pb[I_] = act[I_] && !(hasIns && base + LANE == insPos); })
-            auto gather = [&](LVREF(uint32_t, ceV), LVREF(Win20, W)) {
-                LANES({
-                    const int t = (int)(ceV[I_] >> sh) - base;               // (& 63: the lane in either batch)
-                    const bool same = ceV[I_] == cur[I_].pk;
-                    for (int k = 0; k < 5; ++k) {
-                        const uint32_t a = SHFLF(cur, P.w[k], t), b = SHFLF(prev, P.w[k], t);
-                        W[I_].w[k] = same ? cur[I_].C.w[k] : (t >= 0 ? a : b);
-                    }
-                })
-            };
-            auto compare = [&](LVREF(uint32_t, ceV), LVREF(Win20, W), LVREF(bool, hitV), LVREF(int, fwdV)) {
-                LANES({
-                    const uint32_t q = (uint32_t)(base + LANE), cp = ceV[I_] >> sh;
-                    const bool ok = pb[I_] && cp < q && cp + kMaxDist >= q && ((ceV[I_] ^ cur[I_].ent) & tagMask) == 0;
-                    hitV[I_] = ok && W[I_].w[0] == cur[I_].P.w[0];
-                    fwdV[I_] = hitV[I_] ? win20_fwd(cur[I_].P, W[I_]) : 0;
-                })
-            };
-            gather(rent, W0);
-            STAT_WAIT_LGKM();
-            const unsigned long long ts3 = STAT_NOW(); (void)ts3;
-            STAT(P_CYC_REFRESH, ts3 - ts2);
-            compare(rent, W0, hit, fwd);
-            LANES({ eLane[I_] = LANE + kMinMatch + fwd[I_]; })    // lane index just past a match that starts here
             // ---- 3. requests for the batches to come: the peeked candidates of batch k+1 (every lane loads: its candidate, or
             // its own position when it has none), the window of batch k+2 into registers batch k-1 is done with (its C: its P
-            // still serves this batch's chains; they change places at the end)
+            // still serves this batch; they change places at the end)
             LANES({
                 const uint32_t q1 = (uint32_t)(base + 64 + LANE), pr = next[I_].pk >> sh;
-                const bool pc = pr < q1 && pr + kMaxDist >= q1 && ((next[I_].pk ^ next[I_].ent) & tagMask) == 0;
+                const bool pc = (pr < q1) & (pr + kMaxDist >= q1) & (((next[I_].pk ^ next[I_].ent) & tagMask) == 0);
                 next[I_].C = load_win20(src, (int)(pc ? pr : q1));
                 prev[I_].C = load_win20(src, base + 128 + LANE);
             })
+            const unsigned long long ts3 = STAT_NOW(); (void)ts3;
+            STAT(P_CYC_CMP, ts3 - ts2);
 
-            const uint64_t hits0  = BALLOT(hit[I_]);
-            const unsigned long long ts4 = STAT_NOW(); (void)ts4;
-            STAT(P_CYC_CMP, ts4 - ts3);
-            const uint64_t twins0 = BALLOT(act[I_] && r[I_] >= (uint32_t)firstPos);   // earlier twin inside this batch
-            const uint64_t anyTwins = twins0;
-            const uint64_t special0 = hits0 & BALLOT(fwd[I_] == 16);           // longer than the speculative window: the hop needs its end
-            const int  cur0 = probeStart - base;                  // first probe lane (>= 64: none in this batch)
+            const int  cur0 = probeStart - base;                  // first probe lane (>= 64: none in this batch, only the pending insert)
             const bool re0  = hasRe;
             const uint64_t insBit0 = hasIns ? (1ull << (insPos - base)) : 0;
             int lim0 = sBase + 65 - base; if (lim0 > 63) lim0 = 63;   // probe number <= 65 keeps the stride at 1
-
             uint64_t mm = 0;           // executed match lanes
             int      eL = 0;           // end lane of the last executed match
             uint64_t E = 0;            // executed lanes (probes + inserts)
+            uint64_t probes = 0;
             int      Send = 0;
             bool     finished = false;
-            // ---- 4. the walk, in straight passes: scalar hop over the recorded matches, the executed lanes derived per lane
-            // (walk_pass).  Then: does a probe's candidate lie in a lane of this batch the parser did not execute?  Such lanes
-            // -- all of them at once -- follow the chain of displaced entries down to the first executed lane or to an entry
-            // from before the batch (resolve), fetch that window from the registers and compare again; the walk is redone only
-            // if a probe's hit or length changed, and the result stands once a resolve under the final executed set changes no
-            // probe's candidate (the sequential parse is the one consistent assignment: a lane depends on lower lanes only).
-            // A match longer than the speculative window under the hop, a chain that leaves the registers, or three rounds
-            // without agreement send the batch through the general loop below instead.
-            uint64_t probes = 0;
-            auto walk_pass = [&](const uint64_t hitsM, LVREF(int, eV)) {
+            // the parser over this batch's hits: scalar hop over the recorded matches only, everything else derived per lane
+            auto walk = [&]() {
+                const uint64_t hits = BALLOT(hit[I_]);
+                uint64_t specialLeft = hits & BALLOT(fwd[I_] == 16);    // longer than the speculative window: the hop needs its end
                 LV(int, nextHit);      // first recorded match at or after the end of the match that starts here (64: none)
                 LANES({
-                    const uint64_t ah = (eV[I_] < 64) ? (hitsM >> eV[I_]) : 0;
-                    nextHit[I_] = ah ? eV[I_] + ctz64(ah) : 64;
+                    const uint64_t ah = (eLane[I_] < 64) ? (hits >> eLane[I_]) : 0;
+                    nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
                 })
-                mm = 0; eL = 0;
+                mm = 0; eL = 0; finished = false;
                 int w = 64;
-                if (cur0 < 64) { const uint64_t hm = hitsM & (~0ull << cur0); if (hm) w = ctz64(hm); }
+                if (cur0 < 64) { const uint64_t hm = hits & (~0ull << cur0); if (hm) w = ctz64(hm); }
                 if (w > lim0) w = 64;                                  // (the stride limit concerns the first match only)
                 const unsigned long long tw1 = STAT_NOW(); (void)tw1;
                 if (w < 64) {
-                    const uint64_t low = (w == 0 ? 1ull : 0ull);
-                    do {
-                        for (int u = 0; u < 4; ++u) {
-                            const int n1 = RL(nextHit, w & 63);
-                            mm |= 1ull << (w & 63);
-                            w = (w < 64) ? n1 : 64;
-                        }
-                        STAT(P_HOPS, 4);
-                    } while (w < 64);
-                    mm = (mm & ~1ull) | low;
-                    eL = RL(eV, 63 - __builtin_clzll(mm));
-                }
-                const unsigned long long tw2 = STAT_NOW(); (void)tw2;
-                STAT(P_CYC_HOP, tw2 - tw1);
-                Send = mm ? 64 : min_(64, lim0 + 1);
-                const uint64_t mmL = mm; const int SendL = Send;
-                LV(int, stA);
-                LANES({ stA[I_] = ((mmL >> LANE) & 1) ? eV[I_] : 0; })
-                SCAN_MAX_EXCL(stA);
-                const uint64_t hasPm = BALLOT(stA[I_] > 0);
-                LANES({ stA[I_] = stA[I_] > 0 ? stA[I_] : cur0; })                // where probing resumed before me
-                probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
-                E = probes | insBit0 | (hasPm & BALLOT(stA[I_] == LANE + 2));      // + the ip-2 inserts (lz4.c:1236-1242)
-                STAT(P_CYC_E, STAT_NOW() - tw2);
-            };
-            bool slow;
-            walk_pass(hits0, eLane);
-            slow = (mm & special0) != 0;
-            EMU_CNT(4, slow);
-#if defined(PLZ4_EMU) && defined(PLZ4_EMU_TRACE)
-            if (base < 200) { fprintf(stderr, "base %d cur0 %d probes %llx E %llx twins %llx mm %llx slow %d hasIns %d insPos %d\n", base, cur0, (unsigned long long)probes, (unsigned long long)E, (unsigned long long)twins0, (unsigned long long)mm, (int)slow, (int)hasIns, insPos);
-                for (int l = 0; l < 64; ++l) fprintf(stderr, " l%d r%u pk%u hit%d fwd%d |", l, rent[l] >> sh, cur[l].pk >> sh, (int)hit[l], fwd[l]); fprintf(stderr, "\n"); }
-#endif
-            if (!slow && (twins0 & probes)) {
-                const uint64_t EL0 = E;
-                const uint64_t bad = twins0 & probes & BALLOT(!((EL0 >> (((int)r[I_] - base) & 63)) & 1));
-                if (bad) {
-                    EMU_CNT(5, 1);
-#if defined(PLZ4_EMU) && defined(PLZ4_EMU_TRACE)
-                    if (base == 64) { fprintf(stderr, "base 64 bad %llx probes %llx E %llx twins %llx mm %llx\n", (unsigned long long)bad, (unsigned long long)probes, (unsigned long long)E, (unsigned long long)twins0, (unsigned long long)mm);
-                        for (int l = 0; l < 64; ++l) fprintf(stderr, " l%d r%u pk%u hit%d fwd%d |", l, rent[l] >> sh, cur[l].pk >> sh, (int)hit[l], fwd[l]); fprintf(stderr, "\n"); }
-#endif
-                    LV(uint32_t, ce); LV(Win20, W1);
-                    LANES({ ce[I_] = rent[I_]; })
-                    int it = 0;
-                    for (; it < 3 && !slow; ++it) {
-                        // resolve under E: from the commit's answer down the chain of displaced entries
-                        LV(uint32_t, ce2);
-                        LANES({ ce2[I_] = rent[I_]; })
-                        for (;;) {
-                            const uint64_t EL = E;
-                            const uint64_t mv = BALLOT(pb[I_] && (ce2[I_] >> sh) >= (uint32_t)firstPos && !((EL >> (((int)(ce2[I_] >> sh) - base) & 63)) & 1));   // (an entry of [base, firstPos) is older than the batch)
-                            if (!mv) break;
-                            LANES({ const uint32_t nx = SHFL(rent, (int)(ce2[I_] >> sh) - base); if ((mv >> LANE) & 1) ce2[I_] = nx; })
-                        }
-                        if (!(BALLOT(ce2[I_] != ce[I_]) & probes)) break;          // every probe has the candidate the parser saw
-                        LANES({ ce[I_] = ce2[I_]; })
-                        // an entry from before the previous batch that is not the peeked one: its window is not in the registers
-                        if (BALLOT(pb[I_] && ce[I_] != cur[I_].pk && (ce[I_] >> sh) + 64u < (uint32_t)base) & probes) { slow = true; break; }
-                        LV(bool, hitN); LV(int, fwdN);
-                        gather(ce, W1);
-                        compare(ce, W1, hitN, fwdN);
-                        const uint64_t diff = BALLOT(hitN[I_] != hit[I_] || fwdN[I_] != fwd[I_]) & probes;
-                        LANES({ hit[I_] = hitN[I_]; fwd[I_] = fwdN[I_]; eLane[I_] = LANE + kMinMatch + fwdN[I_]; r[I_] = ce[I_] >> sh; })
-                        if (!diff) break;                                          // same walk, same executed set: consistent
-                        EMU_CNT(6, 1);
-                        const uint64_t hitsN = BALLOT(hit[I_]);
-                        walk_pass(hitsN, eLane);
-                        if (mm & hitsN & BALLOT(fwd[I_] == 16)) slow = true;
-                    }
-                    if (it == 3) slow = true;
-                    if (slow) {                                                    // back to the commit's answer for the general loop
-                        EMU_CNT(7, 1);
-                        compare(rent, W0, hit, fwd);
-                        LANES({ eLane[I_] = LANE + kMinMatch + fwd[I_]; r[I_] = rent[I_] >> sh; })
-                    }
-                }
-            }
-            const unsigned long long tw3 = STAT_NOW(); (void)tw3;
-            if (slow) {
-            uint64_t hits = hits0, twins = twins0, specialLeft = special0;
-            uint64_t cwValid = BALLOT(cand[I_]);                       // lanes whose C holds the window of their rent's position
-            mm = 0; eL = 0; E = 0; Send = 0;
-            STAT(P_REPAIR, 1);
-            // ---- 4. scalar hop over the recorded matches only; everything else is derived per lane
-            LV(int, stA);
-            // after a twin repair at lane b the walk is redone from b only: what it did below b does not depend on b
-            uint64_t keep = 0; int resume = -1;
-            for (;;) {
-                LV(int, nextHit);      // first recorded match at or after the end of the match that starts here (64: none)
-                {
-                    const uint64_t hitsL = hits;
-                    LANES({
-                        const uint64_t ah = (eLane[I_] < 64) ? (hitsL >> eLane[I_]) : 0;
-                        nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
-                    })
-                }
-                mm = keep; eL = 0; finished = false;
-                int w = 64;
-                {
-                    const int start = resume >= 0 ? resume : cur0;     // lane b was a probe: the parser is searching there
-                    if (start < 64) { const uint64_t hm = hits & (~0ull << start); if (hm) w = ctz64(hm); }
-                }
-                if (w < 64 && (mm != 0 || w <= lim0)) {               // (the stride limit concerns the first match only)
                     // Hops come four to a branch.  A hop is: mark the lane, fetch its successor.  Once the walk has ended
                     // (w == 64) the remaining hops of a group only touch bit 0 of the mask, which no hop but the very
                     // first can legitimately set.  Matches longer than the speculative window are not known to the hop: it
@@ -382,15 +247,17 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                                 mm |= 1ull << (w & 63);
                                 w = (w < 64) ? n1 : 64;
                             }
+                            STAT(P_HOPS, 4);
                         } while (w < 64);
                         mm = (mm & ~1ull) | low;
                         const uint64_t sp = mm & specialLeft;
                         if (!sp) break;
+                        EMU_CNT(4, 1);
                         const int ws = ctz64(sp);
                         mm &= (2ull << ws) - 1;                       // what the walk did after it is void
-                        const int p0 = base + ws, c0 = (int)RL(r, ws);
-                        int mc0 = (int)RL(fwd, ws);
-                        if (mc0 == 16) { mc0 += wave_common_len(src, p0 + 20, c0 + 20, matchLimit); WL(fwd, ws, mc0); }
+                        const int p0 = base + ws, c0 = (int)(RL(ce, ws) >> sh);
+                        const int mc0 = 16 + wave_common_len(src, p0 + 20, c0 + 20, matchLimit);
+                        WL(fwd, ws, mc0);
                         specialLeft &= ~(1ull << ws);
                         const int e1 = ws + kMinMatch + mc0;
                         WL(eLane, ws, e1);
@@ -399,101 +266,247 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                         w = hm ? ctz64(hm) : 64;
                         if (w >= 64) break;
                     }
+                    eL = RL(eLane, 63 - __builtin_clzll(mm));
                 }
-                if (mm) eL = RL(eLane, 63 - __builtin_clzll(mm));
-                // ---- 5. which lanes did the sequential parser execute
+                const unsigned long long tw2 = STAT_NOW(); (void)tw2;
+                STAT(P_CYC_HOP, tw2 - tw1);
+                // which lanes did the sequential parser execute: the end of the last executed match below each lane (ends grow
+                // along the walk, so an exclusive prefix maximum over the match lanes is that value)
                 Send = mm ? 64 : min_(64, lim0 + 1);
                 const uint64_t mmL = mm; const int SendL = Send;
-                // end of the last executed match below each lane: ends grow along the walk, so an exclusive
-                // prefix maximum over the match lanes (DPP, no LDS round trip) is that value
+                LV(int, stA);
                 LANES({ stA[I_] = ((mmL >> LANE) & 1) ? eLane[I_] : 0; })
                 SCAN_MAX_EXCL(stA);
                 const uint64_t hasPm = BALLOT(stA[I_] > 0);
                 LANES({ stA[I_] = stA[I_] > 0 ? stA[I_] : cur0; })                // where probing resumed before me
-                const uint64_t probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
+                probes = BALLOT(LANE >= stA[I_] && LANE < SendL && LANE >= cur0);
                 E = probes | insBit0 | (hasPm & BALLOT(stA[I_] == LANE + 2));      // + the ip-2 inserts (lz4.c:1236-1242)
-                if (twins & probes) {
-                    // A probe whose candidate is an earlier lane of this batch is only right if that lane was executed.
-                    // Otherwise the sequential parser saw what that lane displaced (or what *it* displaced, ...):
-                    // repair the first such lane in place and redo the (cheap) hop.
-                    const uint64_t EL = E;
-                    const uint64_t bad = twins & probes & BALLOT(!((EL >> (((int)r[I_] - base) & 63)) & 1));
-                    if (bad) {
-                        EMU_CNT(3, 1);
-                        const int b = ctz64(bad);
-                        uint32_t ce = RL(rent, b);                          // entry lane b displaced
-                        int tl = -1;                                        // the lane whose displaced entry `ce` is
-                        for (;;) {
-                            const uint32_t ci = ce >> sh;
-                            if (ci < (uint32_t)firstPos) break;             // a pre-batch entry
-                            const int t = (int)ci - base;
-                            if ((E >> t) & 1) break;                        // an executed lane of this batch
-                            ce = RL(rent, t);                               // a skipped lane: what it displaced
-                            tl = t;
-                        }
-                        const uint32_t cp = ce >> sh, qb = (uint32_t)(base + b);
-                        int nhit = 0, nfwd = 0;
-                        if (cp + kMaxDist >= qb && ((ce ^ RLF(cur, ent, b)) & tagMask) == 0) {
-                            Win20 Pb; for (int k = 0; k < 5; ++k) Pb.w[k] = RLF(cur, P.w[k], b);
-                            Win20 Cn;
-                            if (cp >= (uint32_t)base) { const int t = (int)cp - base; for (int k = 0; k < 5; ++k) Cn.w[k] = RLF(cur, P.w[k], t); }
-                            // a pre-batch entry was displaced by lane tl, and if that lane took it for a candidate (a twin
-                            // usually repeats the very same bytes) its window already holds what is needed: no memory round trip
-                            else if (tl >= 0 && ((cwValid >> tl) & 1)) { for (int k = 0; k < 5; ++k) Cn.w[k] = RLF(W0, w[k], tl); }
-                            else { Cn = load_win20(src, (int)cp); for (int k = 0; k < 5; ++k) Cn.w[k] = UNI(Cn.w[k]); }
-                            if (Cn.w[0] == Pb.w[0]) { nhit = 1; nfwd = win20_fwd(Pb, Cn); }
-                        }
-                        WL(rent, b, ce); WL(r, b, cp); WL(hit, b, nhit != 0); WL(fwd, b, nfwd);
-                        WL(eLane, b, b + kMinMatch + nfwd);
-                        const uint64_t bit = 1ull << b;
-                        hits = nhit ? (hits | bit) : (hits & ~bit);
-                        specialLeft = (nhit && nfwd == 16) ? (specialLeft | bit) : (specialLeft & ~bit);
-                        twins &= ~bit;
-                        cwValid &= ~bit;                                    // lane b's C no longer belongs to its (new) rent
-                        keep = mm & (bit - 1); resume = b;
-                        continue;
+                STAT(P_CYC_E, STAT_NOW() - tw2);
+            };
+            // the same walk without a branch in it, for the first round: eight hops unconditionally (a hop past the end only
+            // touches bit 0 again), more only if the batch has more matches; matches longer than the speculative window are
+            // taken at that length and reported by the caller's check (a uniform branch costs this machine 80-90 cycles, taken
+            // or not: scripts/micro/branch.hip -- the steady state is written to have a handful of them per batch, not forty)
+#if defined(PLZ4_WALK_SCALAR_E)
+            auto walk_fast = [&](const uint64_t hits) {
+                // per lane: the first recorded match at or after the end of the match that starts here (64: none), and how many
+                // lanes behind it that match covers.  Lane 0 is made the walk's sink: successor 64 (read back as lane 0 by the
+                // hop's & 63), covers nothing -- so a hop past the end changes nothing and needs no test.  A walk that really
+                // starts at lane 0 takes its first hop by hand.
+                LV(int, nextHit); LV(int, covN);
+                LANES({
+                    const uint64_t ah = (eLane[I_] < 64) ? (hits >> eLane[I_]) : 0;
+                    nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
+                    covN[I_] = fwd[I_] + (kMinMatch - 1);               // lanes LANE+1 .. eLane-1
+                })
+                const uint64_t hm = (cur0 < 64) ? (hits & (~0ull << (cur0 & 63))) : 0;
+                int w0 = hm ? ctz64(hm) : 64;
+                w0 = (w0 > lim0) ? 64 : w0;                            // (the stride limit concerns the first match only)
+                const bool first0 = (w0 == 0);
+                const int n0 = RL(nextHit, 0), c0 = RL(covN, 0);
+                LANES({ nextHit[I_] = (LANE == 0) ? 64 : nextHit[I_]; covN[I_] = (LANE == 0) ? 0 : covN[I_]; })
+                int w = first0 ? n0 : w0;
+                uint64_t m = 0;
+                uint64_t cov = first0 ? (((1ull << (c0 & 63)) - 1ull) << 1) : 0;     // (a first match at lane 0 covers c0 <= 19 lanes)
+                const unsigned long long tw1 = STAT_NOW(); (void)tw1;
+                for (int u = 0; u < 8; ++u) {
+                    const int n1 = RL(nextHit, w & 63), cw = RL(covN, w & 63);
+                    m   |= 1ull << (w & 63);
+                    cov |= BFM64(cw, w & 63) << 1;                       // lanes w+1 .. w+cw (a match at lane 63 covers nothing here)
+                    w = n1;
+                }
+                while (w < 64) {
+                    for (int u = 0; u < 4; ++u) {
+                        const int n1 = RL(nextHit, w & 63), cw = RL(covN, w & 63);
+                        m   |= 1ull << (w & 63);
+                        cov |= BFM64(cw, w & 63) << 1;                       // lanes w+1 .. w+cw (a match at lane 63 covers nothing here)
+                        w = n1;
                     }
                 }
-                break;
+                STAT(P_HOPS, 8);
+                mm = (m & ~1ull) | (first0 ? 1ull : 0ull);
+                eL = RL(eLane, (63 - __builtin_clzll(mm | 1ull)) & 63);
+                eL = mm ? eL : 0;
+                finished = false;
+                const unsigned long long tw2 = STAT_NOW(); (void)tw2;
+                STAT(P_CYC_HOP, tw2 - tw1);
+                // the executed lanes, in scalar arithmetic: probes = the lanes from the first probe on that no executed match
+                // covers (a match's own first lane is a probe); the ip-2 insert of a match (lz4.c:1236-1242) is the last but one
+                // lane it covers -- matches are at least 4 long and a covered run ends where its match ends, except the last
+                // one, which may run past lane 63
+                Send = mm ? 64 : min_(64, lim0 + 1);
+                const uint64_t from = (cur0 < 64) ? (~0ull << (cur0 & 63)) : 0;
+                const uint64_t upto = (Send >= 64) ? ~0ull : ((1ull << (Send & 63)) - 1ull);
+                probes = ~cov & from & upto;
+                uint64_t ins = (cov & ~(cov >> 1)) >> 1;               // a run's last lane, one down
+                ins = (eL >= 65) ? (ins & ~(1ull << 62)) : ins;        // the last run is cut off by the batch, not ended ...
+                ins = (eL == 65) ? (ins | (1ull << 63)) : ins;         // ... and ends one lane behind it
+                E = probes | ins | insBit0;
+                STAT(P_CYC_E, STAT_NOW() - tw2);
+            };
+#else
+            auto walk_fast = [&](const uint64_t hits) {
+                LV(int, nextHit);
+                LANES({
+                    const uint64_t ah = (eLane[I_] < 64) ? (hits >> eLane[I_]) : 0;
+                    nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
+                })
+                const uint64_t hm = (cur0 < 64) ? (hits & (~0ull << (cur0 & 63))) : 0;
+                int w = hm ? ctz64(hm) : 64;
+                w = (w > lim0) ? 64 : w;                               // (the stride limit concerns the first match only)
+                const uint64_t low = (w == 0 ? 1ull : 0ull);
+                const bool any = w < 64;
+                uint64_t m = 0;
+                const unsigned long long tw1 = STAT_NOW(); (void)tw1;
+                for (int u = 0; u < 8; ++u) {
+                    const int n1 = RL(nextHit, w & 63);
+                    m |= 1ull << (w & 63);
+                    w = (w < 64) ? n1 : 64;
+                }
+                while (w < 64) {
+                    for (int u = 0; u < 4; ++u) {
+                        const int n1 = RL(nextHit, w & 63);
+                        m |= 1ull << (w & 63);
+                        w = (w < 64) ? n1 : 64;
+                    }
+                }
+                STAT(P_HOPS, 8);
+                mm = any ? ((m & ~1ull) | low) : 0;
+                eL = RL(eLane, (63 - __builtin_clzll(mm | 1ull)) & 63);
+                eL = mm ? eL : 0;
+                finished = false;
+                const unsigned long long tw2 = STAT_NOW(); (void)tw2;
+                STAT(P_CYC_HOP, tw2 - tw1);
+                Send = mm ? 64 : min_(64, lim0 + 1);
+                const uint64_t mmL = mm; const int SendL = Send;
+                LV(int, stA);
+                LANES({ stA[I_] = ((mmL >> LANE) & 1) ? eLane[I_] : 0; })
+                SCAN_MAX_EXCL(stA);
+                const uint64_t hasPm = BALLOT(stA[I_] > 0);
+                LANES({ stA[I_] = stA[I_] > 0 ? stA[I_] : cur0; })
+                probes = BALLOT((LANE >= stA[I_]) & (LANE < SendL) & (LANE >= cur0));
+                E = probes | insBit0 | (hasPm & BALLOT(stA[I_] == LANE + 2));
+                STAT(P_CYC_E, STAT_NOW() - tw2);
+            };
+#endif
+            // ---- 4. first round, straight: walk -> commit -> verify, every step unconditional, ONE question at the end
+            uint64_t committed = 0;
+            bool giveUp = false;
+            {
+                const uint64_t hits1 = BALLOT(hit[I_]);
+                const uint64_t special1 = hits1 & BALLOT(fwd[I_] == 16);
+                walk_fast(hits1);
+                const unsigned long long tc0 = STAT_NOW(); (void)tc0;
+                const uint64_t EL = E;
+                // (a lane that is not executed exchanges a 0: the slot stays as it is)
+                LANES({ rent[I_] = lds_max_rtn(&T[cur[I_].h], ((EL >> LANE) & 1) ? cur[I_].ent : 0u); })
+                committed = EL;
+                const uint64_t upd = probes & BALLOT(rent[I_] != ce[I_]);
+                // (ascending lane order of the atomics on one slot is what makes the returned entry the sequential one: any other
+                // order shows up as a position at or above the lane's own)
+                const uint64_t misorder = EL & BALLOT((rent[I_] >> sh) >= (uint32_t)(base + LANE));
+                const uint64_t noRegs   = upd & BALLOT(rent[I_] != cur[I_].pk && (rent[I_] >> sh) + 64u < (uint32_t)base);
+                LV(bool, hitN); LV(int, fwdN); LV(Win20, Wn);
+                LANES({
+                    const bool u = (upd >> LANE) & 1;
+                    ce[I_] = u ? rent[I_] : ce[I_];
+                    const int t = (int)(ce[I_] >> sh) - base;               // (& 63: the lane in either batch)
+                    const bool same = ce[I_] == cur[I_].pk;
+                    for (int k = 0; k < 5; ++k) {
+                        const uint32_t a = SHFLF(cur, P.w[k], t), b = SHFLF(prev, P.w[k], t);
+                        Wn[I_].w[k] = same ? cur[I_].C.w[k] : (t >= 0 ? a : b);
+                    }
+                })
+                compare(Wn, hitN, fwdN);
+                // (a window that compares equal to its end says nothing about the length behind it: that one is measured again)
+                const uint64_t diff = upd & BALLOT((hitN[I_] != hit[I_]) | (fwdN[I_] != fwd[I_]) | (fwdN[I_] == 16));
+                LANES({
+                    const bool u = (upd >> LANE) & 1;
+                    hit[I_] = u ? hitN[I_] : hit[I_]; fwd[I_] = u ? fwdN[I_] : fwd[I_]; eLane[I_] = LANE + kMinMatch + fwd[I_];
+                })
+                STAT(P_CYC_REFRESH, STAT_NOW() - tc0);
+                EMU_CNT(5, upd != 0);
+                const uint64_t trouble = misorder | noRegs | diff | (mm & special1);
+                if (trouble) {
+                    // ---- rounds of walk -> commit -> verify (the walk with the long matches measured) until one verifies
+                    EMU_CNT(6, 1); STAT(P_REPAIR, 1);
+                    if (misorder | noRegs) { EMU_CNT(2, misorder != 0); EMU_CNT(7, noRegs != 0); giveUp = true; }
+                    for (int round = 1; !giveUp; ++round) {
+                        {                                                      // take the last round's commits back
+                            const uint64_t cm = committed;
+                            LANES({ if ((cm >> LANE) & 1) lds_min(&T[cur[I_].h], rent[I_]); })   // min over a slot's group == its pre-batch value
+                            LDS_ORDER();
+                            committed = 0;
+                        }
+                        if (round == 4) { giveUp = true; break; }
+#if defined(PLZ4_TROUBLE_WALK_FAST)
+                        {
+                            const uint64_t hitsR = BALLOT(hit[I_]);
+                            walk_fast(hitsR);
+                            if (mm & hitsR & BALLOT(fwd[I_] == 16)) walk();    // a match longer than the window under the hop: measured
+                        }
+#else
+                        walk();
+#endif
+                        const uint64_t EL2 = E;
+                        LANES({ if ((EL2 >> LANE) & 1) rent[I_] = lds_max_rtn(&T[cur[I_].h], cur[I_].ent); })
+                        committed = EL2;
+                        const uint64_t upd2 = probes & BALLOT(rent[I_] != ce[I_]);
+                        if (EL2 & BALLOT((rent[I_] >> sh) >= (uint32_t)(base + LANE))) { EMU_CNT(2, 1); giveUp = true; break; }
+                        if (!upd2) break;                                      // every probe read what it had assumed
+                        if (upd2 & BALLOT(rent[I_] != cur[I_].pk && (rent[I_] >> sh) + 64u < (uint32_t)base)) { EMU_CNT(7, 1); giveUp = true; break; }
+                        LANES({
+                            if ((upd2 >> LANE) & 1) ce[I_] = rent[I_];
+                            const int t = (int)(ce[I_] >> sh) - base;
+                            const bool same = ce[I_] == cur[I_].pk;
+                            for (int k = 0; k < 5; ++k) {
+                                const uint32_t a = SHFLF(cur, P.w[k], t), b = SHFLF(prev, P.w[k], t);
+                                Wn[I_].w[k] = same ? cur[I_].C.w[k] : (t >= 0 ? a : b);
+                            }
+                        })
+                        compare(Wn, hitN, fwdN);
+                        const uint64_t diff2 = upd2 & BALLOT(hitN[I_] != hit[I_] || fwdN[I_] != fwd[I_] || fwdN[I_] == 16);
+                        if (!diff2) break;                                     // same walk, same executed set: only offsets moved
+                        LANES({ if ((upd2 >> LANE) & 1) { hit[I_] = hitN[I_]; fwd[I_] = fwdN[I_]; eLane[I_] = LANE + kMinMatch + fwdN[I_]; } })
+                    }
+                }
             }
+            if (giveUp) {
+                if (committed) {
+                    const uint64_t cm = committed;
+                    LANES({ if ((cm >> LANE) & 1) lds_min(&T[cur[I_].h], rent[I_]); })
+                }
+                LDS_FENCE();
+                return kGridGeneric;
             }
-            // lz4.c:1233: a match that ends at or past the last probe position ends the block.  Decided here, from the
-            // final walk: the pass that finished a long match may have been redone after a twin repair, and the redo
-            // sees that match as an ordinary one.
-            finished = (mm != 0) && (base + eL >= lastProbe);
             const unsigned long long ts5 = STAT_NOW(); (void)ts5;
-            STAT(P_CYC_WALK, ts5 - ts4); STAT(P_CYC_SLOW, ts5 - tw3);
+            STAT(P_CYC_WALK, ts5 - ts3);
 
-            // ---- 6. one record per executed match
-            if (mm) {
+            // ---- 5. one record per executed match
+            {
+                // (every lane stores: the ones without a match into the dump entry behind the block's last possible record)
                 const uint64_t mmL = mm; const int at = nseq;
                 LANES({
-                    if ((mmL >> LANE) & 1)
-                        seq[at + LANE_RANK(mmL)] = seq_pack((uint32_t)(base + LANE), (uint32_t)fwd[I_], (uint32_t)(base + LANE) - r[I_]);
+                    const int slot = ((mmL >> LANE) & 1) ? at + LANE_RANK(mmL) : seqDump;
+                    seq[slot] = seq_pack((uint32_t)(base + LANE), (uint32_t)fwd[I_], (uint32_t)(base + LANE) - (ce[I_] >> sh));
                 })
                 nseq += __builtin_popcountll(mm);
-                anchor = base + eL;
+                anchor = mm ? base + eL : anchor;
             }
             if (finished) return kGridDone;
 
-            // ---- 7. parser state after this batch
-            hasIns = false;
-            if (cur0 < 64) hasRe = false;
-            if (mm) {
-                sBase = base + eL + 1; sIter = 0;
-                if (eL - 2 >= 64) { hasIns = true; insPos = base + eL - 2; }
-                if (eL >= Send) { hasRe = true; rePos = base + eL; }       // its re-test is not executed in this batch
-                else sIter = (base + Send) - sBase;                         // lanes eL..Send-1 missed (eL was the re-test)
-            } else if (cur0 < 64) {
-                if (Send > cur0) sIter = (base + Send) - sBase;             // lanes cur0..Send-1 missed
-                else if (re0) { hasRe = true; rePos = base + cur0; }
+            // ---- 6. parser state after this batch
+            {   // (selects, not branches)
+                const bool hm = mm != 0, c0 = cur0 < 64;
+                const bool reM = eL >= Send;                                // with a match: its re-test is not executed in this batch
+                const bool reN = c0 & !(Send > cur0) & re0;                 // without: the pending re-test stays pending
+                const int  sB  = hm ? base + eL + 1 : sBase;
+                const int  sI  = hm ? (reM ? 0 : (base + Send) - sB) : ((c0 & (Send > cur0)) ? (base + Send) - sBase : sIter);
+                const bool nRe = hm ? reM : (c0 ? reN : hasRe);
+                const int  nRp = hm ? base + eL : (reN ? base + cur0 : rePos);
+                hasIns = hm & (eL - 2 >= 64); insPos = hasIns ? base + eL - 2 : insPos;
+                sBase = sB; sIter = sI; hasRe = nRe; rePos = nRp;
             }
-
-            // ---- 8. patch the table to the sequential result
-            const uint64_t EL2 = E;
-            LANES({ if (act[I_] && !((EL2 >> LANE) & 1)) lds_min(&T[cur[I_].h], rent[I_]); })
-            if (anyTwins) { LDS_ORDER(); LANES({ if ((EL2 >> LANE) & 1) lds_max(&T[cur[I_].h], cur[I_].ent); }) }
-            LDS_ORDER();
             width = 64;
             LANES({ prev[I_].P = prev[I_].C; })                            // the window of batch k+2 takes its place
             STAT(P_CYC_TAIL, STAT_NOW() - ts5);

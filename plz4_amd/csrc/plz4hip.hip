@@ -1228,7 +1228,7 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     const bool shared = (ws == nullptr);
     if (shared) ws = &c->l1;
     bool fused = maxLen <= 0 || maxLen > kSeqMaxBlock || getenv("PLZ4HIP_L1_FUSED") != nullptr;
-    const size_t seqStride = round_up((size_t)(maxLen > 0 ? maxLen : 0) / 4 + 2, 64);
+    const size_t seqStride = round_up((size_t)(maxLen > 0 ? maxLen : 0) / 4 + 3, 64);     // + the dump entry (lz4_seq_device.inl)
     const int    maxChunks = (int)((seqStride + kSeqChunk - 1) / kSeqChunk);
     const size_t perBlock  = sizeof(SeqInfo) + (size_t)maxChunks * 8 + seqStride * 8;
     const auto need_for = [&](int per) { return round_up((size_t)per * sizeof(SeqInfo), 256) + 2 * round_up((size_t)per * maxChunks * 4, 256) + (size_t)per * seqStride * 8; };

@@ -29,7 +29,7 @@ int emu_encode_block_seq(const uint8_t* src, int n, uint8_t* dst, int cap, int* 
     using namespace plz4;
     static thread_local uint32_t lds[kHashBytes / 4];
     if (n < 0 || n > kSeqMaxBlock) return -1;
-    uint64_t* seq = (uint64_t*)malloc((size_t)seq_capacity(n) * 8);
+    uint64_t* seq = (uint64_t*)malloc(((size_t)seq_capacity(n) + 1) * 8);       // + the dump entry
     int lastAnchor = 0;
     const int nseq = wave_parse_l1(src, n, lds, seq, &lastAnchor);
     if (nseqOut) *nseqOut = nseq;
