@@ -110,6 +110,62 @@ DEV uint32_t wave_xxh32(const uint8_t* p, int n)
 }
 
 
+// The same digest with the payload staged through LDS: all 64 lanes fetch (16 bytes each, 2 KiB per chunk, the next chunk in
+// flight while this one is consumed), the four accumulator lanes read their words back from LDS.  The four-lane version above
+// waits for a memory round trip every eight rounds; here a round costs its arithmetic.  `lds`: 4 KiB owned by this wave.
+DEV uint32_t wave_xxh32_staged(const uint8_t* p, int n, uint8_t* lds)
+{
+    if (n < 4096) return wave_xxh32(p, n);
+    const int stripes = n >> 4;
+    const int nChunks = (stripes + 127) >> 7;
+    LV(uint32_t, acc); LV(v16u_t, r0); LV(v16u_t, r1);
+    LANES({
+        const int l = LANE & 3;
+        acc[I_] = (l == 0) ? XP1 + XP2 : (l == 1) ? XP2 : (l == 2) ? 0u : 0u - XP1;
+        for (int k = 0; k < 4; ++k) { r0[I_].w[k] = 0; r1[I_].w[k] = 0; }
+        if (LANE < stripes)      r0[I_] = *(const v16u_t*)(p + 16 * LANE);
+        if (64 + LANE < stripes) r1[I_] = *(const v16u_t*)(p + 16 * (64 + LANE));
+    })
+    for (int c = 0; c < nChunks; ++c) {
+        uint8_t* buf = lds + ((c & 1) << 11);
+        LANES({
+            *(v16u_t*)(buf + 16 * LANE) = r0[I_];
+            *(v16u_t*)(buf + 1024 + 16 * LANE) = r1[I_];
+            const int s0 = (c + 1) * 128 + LANE;
+            if (s0 < stripes)      r0[I_] = *(const v16u_t*)(p + 16 * (size_t)s0);
+            if (s0 + 64 < stripes) r1[I_] = *(const v16u_t*)(p + 16 * (size_t)(s0 + 64));
+        })
+        LDS_FENCE();
+        const int cnt = min_(128, stripes - c * 128);
+        LANES({
+            if (LANE < 4) {
+                const uint8_t* q = buf + 4 * LANE;
+                uint32_t a = acc[I_];
+                int s = 0;
+                for (; s + 8 <= cnt; s += 8) {
+                    const uint32_t x0 = *(const uint32_t*)(q), x1 = *(const uint32_t*)(q + 16), x2 = *(const uint32_t*)(q + 32), x3 = *(const uint32_t*)(q + 48);
+                    const uint32_t x4 = *(const uint32_t*)(q + 64), x5 = *(const uint32_t*)(q + 80), x6 = *(const uint32_t*)(q + 96), x7 = *(const uint32_t*)(q + 112);
+                    a = rotl32(a + x0 * XP2, 13) * XP1; a = rotl32(a + x1 * XP2, 13) * XP1;
+                    a = rotl32(a + x2 * XP2, 13) * XP1; a = rotl32(a + x3 * XP2, 13) * XP1;
+                    a = rotl32(a + x4 * XP2, 13) * XP1; a = rotl32(a + x5 * XP2, 13) * XP1;
+                    a = rotl32(a + x6 * XP2, 13) * XP1; a = rotl32(a + x7 * XP2, 13) * XP1;
+                    q += 128;
+                }
+                for (; s < cnt; ++s) { a = rotl32(a + *(const uint32_t*)q * XP2, 13) * XP1; q += 16; }
+                acc[I_] = a;
+            }
+        })
+        LDS_FENCE();
+    }
+    uint32_t h = (uint32_t)n + rotl32(RL(acc, 0), 1) + rotl32(RL(acc, 1), 7) + rotl32(RL(acc, 2), 12) + rotl32(RL(acc, 3), 18);
+    p += (size_t)stripes << 4;
+    int rem = n - (stripes << 4);
+    while (rem >= 4) { h = rotl32(h + UNI(ld32u(p)) * XP3, 17) * XP4; p += 4; rem -= 4; }
+    while (rem)      { h = rotl32(h + (uint32_t)UNI(*p) * XP5, 11) * XP1; p++; rem--; }
+    h ^= h >> 15; h *= XP2; h ^= h >> 13; h *= XP3; h ^= h >> 16;
+    return h;
+}
+
 // Streaming xxHash32, seed 0 (xxh32.XXHZero, internal/pkg/xxh32/xxh32zero.go:58-86 Write, :204-235 Sum32; fed in block order by
 // async/hash.go:99-111).  The state lives in device memory between calls; Write is what the wave does, Sum32 is finished by
 // whoever reads the state back (it does not disturb it).  There is no combine operator for XXH32: the four chains are strictly

@@ -656,43 +656,88 @@ DEV int wave_parse_l1(const uint8_t* __restrict__ src, int n, void* tab, uint64_
 }
 
 // ------------------------------------------------------------------------------------------ EMIT
-// What one sequence is in the output, from its record and the record before it (one lane each).
+// What one sequence is in the output, from its record, the record before it and its catch-up length (one lane each).
+// The catch-up (lz4.c:1105-1109: while ip > anchor && match > lowLimit && ip[-1] == match[-1]; a re-test has ip == anchor) is
+// measured once, by the sizes pass, and kept in a byte per sequence for the write pass (255: longer, measured again).
 struct SeqOut { int anchor, lit, mlen, extL, extM, size; uint32_t off; };
-DEV SeqOut seq_measure(const uint8_t* __restrict__ src, uint64_t rec, uint64_t prev, bool first)
+DEV int seq_anchor(uint64_t prev, bool first) { return first ? 0 : (int)seq_pos(prev) + kMinMatch + (int)seq_fwd(prev); }
+DEV SeqOut seq_layout(uint64_t rec, int anchor, int bk)
 {
     SeqOut o;
     const int pos = (int)seq_pos(rec), fwd = (int)seq_fwd(rec);
     o.off = seq_off(rec);
-    o.anchor = first ? 0 : (int)seq_pos(prev) + kMinMatch + (int)seq_fwd(prev);
-    // catch-up (lz4.c:1105-1109): while ip > anchor && match > lowLimit && ip[-1] == match[-1].  A re-test has ip == anchor.
-    const int cnd = pos - (int)o.off;
-    const int maxBack = min_(pos - o.anchor, cnd);
-    int bk = 0;
-    bool open = true;
-    while (open && bk + 4 <= maxBack) {
-        const uint32_t x = ld32u(src + pos - 4 - bk) ^ ld32u(src + cnd - 4 - bk);
-        if (x) { bk += __builtin_clz(x) >> 3; open = false; } else bk += 4;
-    }
-    while (open && bk < maxBack && src[pos - 1 - bk] == src[cnd - 1 - bk]) ++bk;
-    o.lit  = pos - bk - o.anchor;
+    o.anchor = anchor;
+    o.lit  = pos - bk - anchor;
     o.mlen = fwd + bk;
     o.extL = o.lit  >= 15 ? (o.lit  - 15) / 255 + 1 : 0;
     o.extM = o.mlen >= 15 ? (o.mlen - 15) / 255 + 1 : 0;
     o.size = 1 + o.extL + o.lit + 2 + o.extM;
     return o;
 }
+// the catch-up from `bk` bytes on (the first step below has compared that many), at most maxBack
+DEV int seq_backext_from(const uint8_t* __restrict__ src, int pos, int cnd, int maxBack, int bk)
+{
+    bool open = true;
+    while (open && bk + 4 <= maxBack) {
+        const uint32_t x = ld32u(src + pos - 4 - bk) ^ ld32u(src + cnd - 4 - bk);
+        if (x) { bk += __builtin_clz(x) >> 3; open = false; } else bk += 4;
+    }
+    while (open && bk < maxBack && src[pos - 1 - bk] == src[cnd - 1 - bk]) ++bk;
+    return bk;
+}
+// its first four bytes without a branch: the dwords in front of the two positions (clamped to the block's start, shifted so
+// that the byte right before the position is the top one), equal leading bytes of their XOR, at most maxBack
+DEV int seq_backext4(const uint8_t* __restrict__ src, int pos, int cnd, int maxBack, bool* more)
+{
+    const int pa = max_(pos - 4, 0), ca = max_(cnd - 4, 0);
+    const uint32_t xa = ld32u(src + pa) << ((8 * (4 - (pos - pa))) & 31), xc = ld32u(src + ca) << ((8 * (4 - (cnd - ca))) & 31);
+    const uint32_t x = xa ^ xc;
+    const int e4 = x ? (__builtin_clz(x) >> 3) : 4;
+    *more = (e4 == 4) & (maxBack > 4);
+    return min_(e4, max_(min_(maxBack, 4), 0));
+}
 
-// bytes of the sequences [c*kSeqChunk, min(nseq, (c+1)*kSeqChunk)) of a block
-DEV uint32_t seq_emit_sizes(const uint8_t* __restrict__ src, const uint64_t* __restrict__ seq, int nseq, int c)
+// bytes of the sequences [c*kSeqChunk, min(nseq, (c+1)*kSeqChunk)) of a block; their catch-up lengths go to bkOut[].
+// Four sequences per lane and trip: their loads are independent, so one memory round trip serves 256 sequences.
+DEV uint32_t seq_emit_sizes(const uint8_t* __restrict__ src, const uint64_t* __restrict__ seq, uint8_t* __restrict__ bkOut, int nseq, int c)
 {
     const int i0 = c * kSeqChunk, i1 = min_(nseq, i0 + kSeqChunk);
     LV(int, acc);
     LANES({ acc[I_] = 0; })
-    for (int i = i0; i < i1; i += 64) {
-        LANES({
-            const int k = i + LANE;
-            if (k < i1) acc[I_] += seq_measure(src, seq[k], k ? seq[k - 1] : 0, k == 0).size;
+    for (int i = i0; i < i1; i += 256) {
+        LV(uint64_t, rec0); LV(uint64_t, rec1); LV(uint64_t, rec2); LV(uint64_t, rec3);
+        LV(int, bk0); LV(int, bk1); LV(int, bk2); LV(int, bk3);
+        LV(int, an0); LV(int, an1); LV(int, an2); LV(int, an3);
+        LV(bool, mo0); LV(bool, mo1); LV(bool, mo2); LV(bool, mo3);
+#define SEQ_SZ_STEP(U, REC, BK, AN, MO) \
+        LANES({ \
+            const int k_ = min_(i + (U) * 64 + LANE, i1 - 1); \
+            REC[I_] = seq[k_]; \
+            AN[I_]  = seq_anchor(k_ ? seq[k_ - 1] : 0, k_ == 0); \
+            const int pos_ = (int)seq_pos(REC[I_]), cnd_ = pos_ - (int)seq_off(REC[I_]); \
+            bool m_; \
+            BK[I_] = seq_backext4(src, pos_, cnd_, min_(pos_ - AN[I_], cnd_), &m_); \
+            MO[I_] = m_; \
         })
+        SEQ_SZ_STEP(0, rec0, bk0, an0, mo0) SEQ_SZ_STEP(1, rec1, bk1, an1, mo1) SEQ_SZ_STEP(2, rec2, bk2, an2, mo2) SEQ_SZ_STEP(3, rec3, bk3, an3, mo3)
+#undef SEQ_SZ_STEP
+        if (BALLOT(mo0[I_] | mo1[I_] | mo2[I_] | mo3[I_])) {               // a catch-up beyond four bytes (rare): the loop
+#define SEQ_SZ_MORE(REC, BK, AN, MO) \
+            LANES({ if (MO[I_]) { const int pos_ = (int)seq_pos(REC[I_]), cnd_ = pos_ - (int)seq_off(REC[I_]); \
+                                  BK[I_] = seq_backext_from(src, pos_, cnd_, min_(pos_ - AN[I_], cnd_), 4); } })
+            SEQ_SZ_MORE(rec0, bk0, an0, mo0) SEQ_SZ_MORE(rec1, bk1, an1, mo1) SEQ_SZ_MORE(rec2, bk2, an2, mo2) SEQ_SZ_MORE(rec3, bk3, an3, mo3)
+#undef SEQ_SZ_MORE
+        }
+#define SEQ_SZ_FIN(U, REC, BK, AN) \
+        LANES({ \
+            const int k_ = i + (U) * 64 + LANE; \
+            if (k_ < i1) { \
+                acc[I_] += seq_layout(REC[I_], AN[I_], BK[I_]).size; \
+                bkOut[k_] = (uint8_t)min_(BK[I_], 255); \
+            } \
+        })
+        SEQ_SZ_FIN(0, rec0, bk0, an0) SEQ_SZ_FIN(1, rec1, bk1, an1) SEQ_SZ_FIN(2, rec2, bk2, an2) SEQ_SZ_FIN(3, rec3, bk3, an3)
+#undef SEQ_SZ_FIN
     }
     SCAN_INCL(acc);
     return (uint32_t)RL(acc, 63);
@@ -737,7 +782,7 @@ DEV void lane_copy(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, int l
 // Writes chunk c of a block at dst + chunkOff (token, literal length bytes, literals, offset, match length bytes per sequence:
 // lz4.c:1112-1226); the wave that writes the last chunk (or chunk 0 of a block without sequences) also writes the last
 // literals (lz4.c:1302-1329).  Long literal runs and long length-byte runs are left to the whole wave.
-DEV void seq_emit_write(const uint8_t* __restrict__ src, int n, const uint64_t* __restrict__ seq, int nseq, int lastAnchor, int c,
+DEV void seq_emit_write(const uint8_t* __restrict__ src, int n, const uint64_t* __restrict__ seq, const uint8_t* __restrict__ bkIn, int nseq, int lastAnchor, int c,
                         uint32_t chunkOff, uint8_t* __restrict__ dst)
 {
     const int i0 = c * kSeqChunk, i1 = min_(nseq, i0 + kSeqChunk);
@@ -746,7 +791,13 @@ DEV void seq_emit_write(const uint8_t* __restrict__ src, int n, const uint64_t* 
         LV(SeqOut, so); LV(int, tok);
         LANES({
             const int k = i + LANE;
-            if (k < i1) so[I_] = seq_measure(src, seq[k], k ? seq[k - 1] : 0, k == 0);
+            if (k < i1) {
+                const uint64_t rec = seq[k];
+                const int an = seq_anchor(k ? seq[k - 1] : 0, k == 0);
+                int bk = (int)bkIn[k];
+                if (bk == 255) { const int pos = (int)seq_pos(rec), cnd = pos - (int)seq_off(rec); bk = seq_backext_from(src, pos, cnd, min_(pos - an, cnd), 0); }
+                so[I_] = seq_layout(rec, an, bk);
+            }
             else { so[I_].anchor = 0; so[I_].lit = 0; so[I_].mlen = 0; so[I_].extL = 0; so[I_].extM = 0; so[I_].size = 0; so[I_].off = 0; }
             tok[I_] = so[I_].size;
         })

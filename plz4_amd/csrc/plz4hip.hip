@@ -67,6 +67,7 @@ struct CodecArgs {
     SeqInfo*        l1Info;                                  // per block
     uint64_t*       l1Seq;      int64_t l1SeqStride;         // sequence records, entries per block
     uint32_t*       l1ChunkBytes; uint32_t* l1ChunkOff; int l1MaxChunks;   // per block: bytes of / before every chunk of 1024 sequences
+    uint8_t*        l1Bk;                                    // per sequence: its catch-up length (l1SeqStride bytes per block)
     int             l1MaxLen;                                // what the workspace was sized for
 };
 
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void k_l1_sizes(CodecArgs a)
     const uint64_t* seq = a.l1Seq + (int64_t)i * a.l1SeqStride;
     const int nChunks = (nseq + kSeqChunk - 1) / kSeqChunk;
     for (int c = wave; c < nChunks; c += nW) {
-        const uint32_t v = seq_emit_sizes(s, seq, nseq, c);
+        const uint32_t v = seq_emit_sizes(s, seq, a.l1Bk + (int64_t)i * a.l1SeqStride, nseq, c);
         if ((threadIdx.x & 63u) == 0) a.l1ChunkBytes[(int64_t)i * a.l1MaxChunks + c] = v;
     }
 }
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void k_l1_write(CodecArgs a)
         const uint64_t* seq = a.l1Seq + (int64_t)i * a.l1SeqStride;
         const int nChunks = (inf.nseq + kSeqChunk - 1) / kSeqChunk;
         for (int c = wave; c < (nChunks ? nChunks : 1); c += nW)
-            seq_emit_write(s, n, seq, inf.nseq, inf.lastAnchor, c, nChunks ? a.l1ChunkOff[(int64_t)i * a.l1MaxChunks + c] : 0u, out);
+            seq_emit_write(s, n, seq, a.l1Bk + (int64_t)i * a.l1SeqStride, inf.nseq, inf.lastAnchor, c, nChunks ? a.l1ChunkOff[(int64_t)i * a.l1MaxChunks + c] : 0u, out);
     } else if (!a.rawMode && n > 0) {
         const int slice = (((n + nW - 1) / nW) + 15) & ~15;
         const int off = wave * slice;
@@ -216,13 +217,14 @@ __global__ __launch_bounds__(256) void k_l1_write(CodecArgs a)
 // records with block checksums: xxh32 over the payload as stored (blk.go:98-102), one wave per block
 __global__ __launch_bounds__(256) void k_l1_finish(CodecArgs a)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t stagebuf[4][4096];
     const int i = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     if (i >= a.nBlocks) return;
     const int gi = a.blk0 + i;
     const SeqInfo inf = a.l1Info[i];
     const int c = inf.total ? inf.total : block_len(a, gi);
     uint8_t* rec = a.dst + (int64_t)gi * a.dstStride;
-    const uint32_t x = wave_xxh32(rec + 4, c);
+    const uint32_t x = wave_xxh32_staged(rec + 4, c, stagebuf[threadIdx.x >> 6]);
     if ((threadIdx.x & 63u) == 0) { st32u(rec + 4 + c, x); a.result[gi] = c + 8; }
 }
 
@@ -1230,8 +1232,8 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     bool fused = maxLen <= 0 || maxLen > kSeqMaxBlock || getenv("PLZ4HIP_L1_FUSED") != nullptr;
     const size_t seqStride = round_up((size_t)(maxLen > 0 ? maxLen : 0) / 4 + 3, 64);     // + the dump entry (lz4_seq_device.inl)
     const int    maxChunks = (int)((seqStride + kSeqChunk - 1) / kSeqChunk);
-    const size_t perBlock  = sizeof(SeqInfo) + (size_t)maxChunks * 8 + seqStride * 8;
-    const auto need_for = [&](int per) { return round_up((size_t)per * sizeof(SeqInfo), 256) + 2 * round_up((size_t)per * maxChunks * 4, 256) + (size_t)per * seqStride * 8; };
+    const size_t perBlock  = sizeof(SeqInfo) + (size_t)maxChunks * 8 + seqStride * 9;
+    const auto need_for = [&](int per) { return round_up((size_t)per * sizeof(SeqInfo), 256) + 2 * round_up((size_t)per * maxChunks * 4, 256) + (size_t)per * seqStride * 9; };
     int per = nb;
     if (!fused && need_for(nb) > ws->bytes) {
         size_t freeB = 0, totalB = 0;
@@ -1271,6 +1273,7 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     a.l1ChunkBytes = (uint32_t*)(ws->d + round_up((size_t)per * sizeof(SeqInfo), 256));
     a.l1ChunkOff   = (uint32_t*)((uint8_t*)a.l1ChunkBytes + round_up((size_t)per * maxChunks * 4, 256));
     a.l1Seq        = (uint64_t*)((uint8_t*)a.l1ChunkOff + round_up((size_t)per * maxChunks * 4, 256));
+    a.l1Bk         = (uint8_t*)(a.l1Seq + (size_t)per * seqStride);
     for (int g0 = 0; g0 < nb; g0 += per) {
         const int ng = nb - g0 < per ? nb - g0 : per;
         a.blk0 = g0; a.nBlocks = ng;

@@ -36,11 +36,12 @@ int emu_encode_block_seq(const uint8_t* src, int n, uint8_t* dst, int cap, int* 
     const int nChunks = (nseq + kSeqChunk - 1) / kSeqChunk;
     uint32_t* cb = (uint32_t*)malloc((size_t)(nChunks + 1) * 4);
     uint32_t* co = (uint32_t*)malloc((size_t)(nChunks + 1) * 4);
+    uint8_t* bk = (uint8_t*)malloc((size_t)seq_capacity(n) + 1);
     co[0] = 0;
-    for (int c = 0; c < nChunks; ++c) cb[c] = seq_emit_sizes(src, seq, nseq, c);
+    for (int c = 0; c < nChunks; ++c) cb[c] = seq_emit_sizes(src, seq, bk, nseq, c);
     const int total = seq_emit_scan(cb, co, nseq, lastAnchor, n, cap);
-    if (total > 0) for (int c = 0; c < (nChunks ? nChunks : 1); ++c) seq_emit_write(src, n, seq, nseq, lastAnchor, c, co[c], dst);
-    free(seq); free(cb); free(co);
+    if (total > 0) for (int c = 0; c < (nChunks ? nChunks : 1); ++c) seq_emit_write(src, n, seq, bk, nseq, lastAnchor, c, co[c], dst);
+    free(seq); free(cb); free(co); free(bk);
     return total;
 }
 
@@ -64,7 +65,13 @@ int emu_decode_block(const uint8_t* src, int n, uint8_t* dst, int cap)
     return same ? r1 : -999999;
 }
 
-uint32_t emu_xxh32(const uint8_t* p, int n) { return plz4::wave_xxh32(p, n); }
+// both forms of the digest (four lanes straight from memory; staged through LDS): they must agree
+uint32_t emu_xxh32(const uint8_t* p, int n)
+{
+    static thread_local __attribute__((aligned(16))) uint8_t lds[4096];
+    const uint32_t a = plz4::wave_xxh32(p, n), b = plz4::wave_xxh32_staged(p, n, lds);
+    return a == b ? a : ~a;
+}
 
 // streaming content checksum: the pieces of `p` (piece k = lens[k] bytes) written one after the other, then Sum32
 uint32_t emu_xxh32_stream(const uint8_t* p, const int* lens, int nPieces)
