@@ -32,10 +32,17 @@ type BatchDecompressor interface {
 	DecodeRecords(rec, dst [][]byte, bsz int, blockChecksum bool) (n []int, status []int, err error)
 }
 
+// BatchDecompressorRaw: raw LZ4 blocks, n[i] < 0 is liblz4's error code (what async/batch_hip.go hands the reader's blocks to:
+// the frame reader has taken the size word and the checksum off already).
+type BatchDecompressorRaw interface {
+	DecompressBatch(src, dst [][]byte) (n []int, err error)
+}
+
 type LevelT int
 
-// One engine per process over EVERY GPU of the node (plz4hip_mgpu, section D of plz4hip.h): block i of a batch runs on device
-// i mod G, each device behind its own ctx, so concurrent writers are serialised per device only -- not behind one global ctx.
+// One engine per process over EVERY GPU of the node (plz4hip_mgpu, section D of plz4hip.h): the blocks of a batch are dealt round
+// robin over the devices (the device that takes a call's block 0 rotates from call to call, so one-block calls from many
+// goroutines spread over the GPUs), each device behind its own ctx and its own lock -- the handle itself takes none for these calls.
 // PLZ4_HIP_DEVICES=0,2,5 restricts the set (default: all of them).
 var (
 	once sync.Once
@@ -90,6 +97,14 @@ func (hipDecompressor) Decompress(src, dst []byte) (int, error) {
 	return n[0], nil
 }
 
+func (hipDecompressor) DecompressBatch(src, dst [][]byte) ([]int, error) {
+	e, err := engine()
+	if err != nil {
+		return nil, err
+	}
+	return e.DecompressBatch(src, dst)
+}
+
 func (hipDecompressor) DecodeRecords(rec, dst [][]byte, bsz int, blockChecksum bool) ([]int, []int, error) {
 	e, err := engine()
 	if err != nil {
@@ -104,7 +119,9 @@ type DictT struct {
 	dev  *plz4hip.Dict // plz4hip_dict_create(Data), built on first use
 }
 
-func (d *DictT) device(e *plz4hip.Ctx) (*plz4hip.Dict, error) {
+// device: the dictionary's device-side context.  A plz4hip_dict belongs to the ctx that created it, so dictionary / linked calls
+// all go through device 0's ctx (e.Ctx(0) below and at every call site): they are stateful per frame anyway and do not deal.
+func (d *DictT) device(e *plz4hip.Multi) (*plz4hip.Dict, error) {
 	if d == nil {
 		return nil, nil
 	}

@@ -31,8 +31,12 @@ var (
 	ErrEngine        = errors.New("plz4hip engine failure")                             // never mapped to a stored block
 )
 
-// Ctx is one plz4hip_ctx (one device, internal staging, serialised by the library).
-type Ctx struct{ p *C.plz4hip_ctx }
+// Ctx is one plz4hip_ctx (one device, internal staging, serialised by the library).  borrowed: the ctx belongs to a Multi
+// (plz4hip_mgpu_ctx hands out the handle's own pointers): Close leaves it alone, Multi.Close destroys it.
+type Ctx struct {
+	p        *C.plz4hip_ctx
+	borrowed bool
+}
 
 func NewCtx(device int) (*Ctx, error) {
 	var p *C.plz4hip_ctx
@@ -45,10 +49,19 @@ func NewCtx(device int) (*Ctx, error) {
 }
 
 func (c *Ctx) Close() {
-	if c.p != nil {
+	if c.p != nil && !c.borrowed {
 		C.plz4hip_ctx_destroy(c.p)
-		c.p = nil
 	}
+	c.p = nil
+}
+
+// Trim gives back what the ctx keeps between calls: pinned host + device staging, the level-1 and HC workspaces
+// (plz4hip_ctx_trim).  The HC levels hold tens of GiB after a large call.
+func (c *Ctx) Trim() error {
+	if rc := C.plz4hip_ctx_trim(c.p); rc != C.PLZ4HIP_OK {
+		return c.engineErr(rc)
+	}
+	return nil
 }
 
 func CompressBound(sz int) int { return int(C.plz4hip_compress_bound(C.int(sz))) } // == clz4.CompressBound
@@ -375,12 +388,22 @@ func NewMulti(devices []int) (*Multi, error) {
 		return nil, fmt.Errorf("%w: plz4hip_mgpu_create = %d", ErrEngine, int(rc))
 	}
 	for k := range devices {
-		m.ctxs = append(m.ctxs, &Ctx{p: C.plz4hip_mgpu_ctx(m.p, C.int(k))})
+		m.ctxs = append(m.ctxs, &Ctx{p: C.plz4hip_mgpu_ctx(m.p, C.int(k)), borrowed: true})
 	}
 	return m, nil
 }
 
 func (m *Multi) Close()         { C.plz4hip_mgpu_destroy(m.p); m.p = nil }
+
+// Trim: Ctx.Trim on every device.
+func (m *Multi) Trim() error {
+	for _, c := range m.ctxs {
+		if err := c.Trim(); err != nil {
+			return err
+		}
+	}
+	return nil
+}
 func (m *Multi) Ctx(k int) *Ctx { return m.ctxs[k%len(m.ctxs)] }
 func (m *Multi) err(rc C.int) error {
 	return fmt.Errorf("%w: %d: %s", ErrEngine, int(rc), C.GoString(C.plz4hip_mgpu_last_error(m.p)))

@@ -708,6 +708,10 @@ __global__ __launch_bounds__(64) void k_hc12_parse(CodecArgs a)
         const uint8_t* s   = a.src + (int64_t)i * a.srcStride;
         const Hc12F*   F   = a.h12F + (int64_t)g * a.h12FStride;
         const uint16_t* ch = a.h12Chain + (int64_t)g * a.h12ChainStride;
+        if (plz4_readfirstlane(*(volatile int32_t*)a.h12Err)) {               // the search kernel gave up on this group (spin guard):
+            if ((threadIdx.x & 63u) == 0) a.result[i] = PLZ4HIP_E_DEVICE;     // its F is not to be trusted -- an engine failure, not a result
+            continue;
+        }
         if (a.rawMode) {
             const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
             const int r = hc12_parse(s, n, a.dst + (int64_t)i * a.dstStride, cap, F, ch, w);
@@ -828,6 +832,17 @@ __global__ __launch_bounds__(1024) void k_scan(const int32_t* __restrict__ len, 
 }
 
 // Bytes to hand back per block of a host call: the result if positive (sizes), nothing for 0 / error codes.
+// plz4hip_dev_compress: the lengths live on the device and the workspaces are sized from the caller's maxLen.  A private copy with
+// every length outside [0, maxLen] replaced by 0 is what the kernels see; such a block's result becomes PLZ4HIP_E_ARG afterwards.
+__global__ __launch_bounds__(256) void k_check_len(const int32_t* __restrict__ srcLen, int maxLen, int n, int32_t* __restrict__ lenOut, int32_t* __restrict__ result, int after)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool bad = srcLen[i] < 0 || srcLen[i] > maxLen;
+    if (!after) lenOut[i] = bad ? 0 : srcLen[i];
+    else if (bad) result[i] = PLZ4HIP_E_ARG;
+}
+
 __global__ __launch_bounds__(256) void k_out_len(const int32_t* __restrict__ res, int32_t* __restrict__ len, int n)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -844,7 +859,7 @@ __global__ __launch_bounds__(256) void k_move_records(const uint8_t* __restrict_
 {
     const int      i = blockIdx.x;
     const int      n = len[i];
-    if (dstOff[i] + n > dstCap) return;      // caller sees the overflow as recOff[n] > bodyCap
+    if (n <= 0 || dstOff[i] < 0 || dstOff[i] + n > dstCap) return;      // (an overflow shows to the caller as recOff[n] > bodyCap)
     const uint8_t* s = src + (srcOff ? srcOff[i] : (int64_t)i * stride);
     uint8_t*       d = dst + dstOff[i];
     const int full = n & ~15;
@@ -886,6 +901,7 @@ struct plz4hip_ctx {
     // ordered across streams on the device like the HC workspaces
     L1Ws         l1;
     hipEvent_t   l1Done = nullptr; hipStream_t l1Stream = nullptr; bool l1Pending = false;
+    int32_t*     d_lenCopy = nullptr; int lenCopyCap = 0;      // plz4hip_dev_compress: the sanitised block lengths of the last call
 };
 
 // == clz4.DictCtx (clz4.go:96-120): a private device copy of the last 64 KiB of the dictionary + the LZ4_loadDictSlow table.
@@ -1027,6 +1043,12 @@ int hc_leave(plz4hip_ctx* c, hipStream_t s)
     return PLZ4HIP_OK;
 }
 
+// What an HC call may take for its per-block workspaces (chains, lists, search results) when PLZ4HIP_HC_BUDGET_GIB does not say:
+// a quarter of what is free, at most 64 GiB.  A library call that by default walks off with most of the card is not a drop-in
+// (round 2 took three quarters); callers that own the GPU raise the budget, and plz4hip_ctx_trim gives the memory back.  More
+// blocks per group is faster for these kernels (they live on blocks in flight), so a dedicated machine should set it.
+size_t hc_default_budget(size_t freeBytes) { const size_t q = freeBytes / 4, cap = (size_t)64 << 30; return q < cap ? q : cap; }
+
 // Level 12 on independent blocks without dictionary runs in three phases per group of blocks (lz4hc12_device.inl):
 // chain -> search results -> parser.  Per block the group workspace holds the chain (2 B per position) and F (8 B per
 // position); the group size follows from the memory set aside (PLZ4HIP_HC12_GROUP overrides, for tests).
@@ -1038,10 +1060,10 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
     pl->perBlock = (size_t)pl->chainStride * 2 + (size_t)pl->chainStride * 4 + ((size_t)pl->chainStride + 8) * 4 + (size_t)kHcHashEntries * 4 + (size_t)pl->fStride * 8;
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
-    // up to three quarters of what is free (and whatever the ctx holds already): the parser runs one wave per block, so the more
-    // blocks a group has (up to three waves per SIMD: 3072), the better its latency is hidden -- 4096 blocks in two groups of 2048
-    // instead of four of 1024: 1418 -> 1664 MiB/s.  plz4hip_ctx_trim gives the memory back.
-    size_t budget = (freeB + c->h12Bytes) / 4 * 3;
+    // hc_default_budget of what is free (and whatever the ctx holds already) unless PLZ4HIP_HC_BUDGET_GIB says more: the parser runs
+    // one wave per block, so the more blocks a group has (up to three waves per SIMD: 3072), the better its latency is hidden --
+    // 4096 blocks in two groups of 2048 instead of four of 1024: 1418 -> 1664 MiB/s.  plz4hip_ctx_trim gives the memory back.
+    size_t budget = hc_default_budget(freeB + c->h12Bytes);
     if (const char* v = getenv("PLZ4HIP_HC_BUDGET_GIB")) { const long g = atol(v); if (g >= 1) budget = (size_t)g << 30; }
     if (budget < c->h12Bytes) budget = c->h12Bytes;
     int64_t grp = (int64_t)(budget / pl->perBlock);
@@ -1107,6 +1129,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         if (const char* v = getenv("PLZ4HIP_HC12_IDLE")) a.h12Idle = atoi(v);
         const int nGroups = (nb + pl.group - 1) / pl.group;
         const int per = (nb + nGroups - 1) / nGroups;                     // groups of equal size (<= pl.group)
+        HIPCHK(c, hipMemsetAsync(a.h12Err, 0, 4, s));                      // the give-up flag is per call (k_hc12_parse reports it per block)
         for (int g0 = 0; g0 < nb; g0 += per) {
             const int ng = nb - g0 < per ? nb - g0 : per;
             a.blk0 = g0; a.nBlocks = ng;
@@ -1136,12 +1159,11 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             const int64_t stride = (int64_t)round_up((size_t)maxLen + 1, 1024);
             size_t freeB = 0, totalB = 0;
             if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
-            size_t budget = (freeB + c->h12Bytes) / 2;                   // the chain alone: half of what is free, at most 96 GiB
-            if (budget > ((size_t)96 << 30)) budget = (size_t)96 << 30;
+            size_t budget = hc_default_budget(freeB + c->h12Bytes);      // the chain alone
             // the lists are worth more memory than that: these kernels live on the number of blocks in flight (7 waves per SIMD
-            // fit), and 4096 blocks of 4 MiB with their lists (40 MiB each) are 160 GiB -- up to three quarters of what is free;
+            // fit), and 4096 blocks of 4 MiB with their lists (40 MiB each) are 160 GiB: a machine that is there for this sets PLZ4HIP_HC_BUDGET_GIB;
             // plz4hip_ctx_trim gives it back.  What the ctx already holds is used in any case.
-            size_t budgetLists = (freeB + c->h12Bytes) / 4 * 3;
+            size_t budgetLists = hc_default_budget(freeB + c->h12Bytes);
             if (const char* v = getenv("PLZ4HIP_HC_BUDGET_GIB")) { const long g = atol(v); if (g >= 1) budget = budgetLists = (size_t)g << 30; }
             if (budget < c->h12Bytes) budget = c->h12Bytes;
             if (budgetLists < c->h12Bytes) budgetLists = c->h12Bytes;
@@ -1377,6 +1399,7 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     if (c->d_h12) hipFree(c->d_h12);
     if (c->l1Pending) hipEventSynchronize(c->l1Done);
     if (c->l1.d) hipFree(c->l1.d);
+    if (c->d_lenCopy) hipFree(c->d_lenCopy);
     if (c->l1Done) hipEventDestroy(c->l1Done);
     if (c->hcDone) hipEventDestroy(c->hcDone);
     if (c->hashStream) { hipStreamSynchronize(c->hashStream); hipStreamDestroy(c->hashStream); }
@@ -1430,8 +1453,26 @@ int plz4hip_dev_compress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t s
     a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCap = dstCap;
     a.result = result; a.nBlocks = nBlocks;
     a.dictLen = -1; a.prevTailLen = -1;
-    if (is_hc_level(level)) { a.level = level; return launch_hc(c, s, a, nBlocks, maxLen, 1); }
-    return launch_l1(c, s, a, nBlocks, maxLen, 1, nullptr);              // (maxLen <= 0: lengths unknown to the host -> fused kernels)
+    if (maxLen > 0) {
+        // the kernels index per-block workspaces sized from maxLen: they read lengths that were checked against it
+        if (nBlocks > c->lenCopyCap) {
+            HIPCHK(c, hipDeviceSynchronize());                           // (a copy an earlier call still reads is not freed under it)
+            if (c->d_lenCopy) hipFree(c->d_lenCopy);
+            c->d_lenCopy = nullptr; c->lenCopyCap = 0;
+            if (hipMalloc((void**)&c->d_lenCopy, (size_t)nBlocks * 4 + 1024) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "plz4hip_dev_compress: length copy");
+            c->lenCopyCap = nBlocks + 256;
+        }
+        hipLaunchKernelGGL(k_check_len, dim3((nBlocks + 255) / 256), dim3(256), 0, s, srcLen, maxLen, nBlocks, c->d_lenCopy, result, 0);
+        a.srcLen = c->d_lenCopy;
+    }
+    int rc;
+    if (is_hc_level(level)) { a.level = level; rc = launch_hc(c, s, a, nBlocks, maxLen, 1); }
+    else rc = launch_l1(c, s, a, nBlocks, maxLen, 1, nullptr);           // (maxLen <= 0: lengths unknown to the host -> fused kernels)
+    if (rc == PLZ4HIP_OK && maxLen > 0) {
+        hipLaunchKernelGGL(k_check_len, dim3((nBlocks + 255) / 256), dim3(256), 0, s, srcLen, maxLen, nBlocks, c->d_lenCopy, result, 1);
+        HIPCHK(c, hipGetLastError());
+    }
+    return rc;
 }
 
 int plz4hip_dev_decompress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,8 +47,10 @@ struct DevGuard {
 
 struct plz4hip_mgpu {
     std::vector<Shard> sh;
-    std::mutex mu;
+    std::mutex mu;                      // the device-resident frame calls: they share the shards' scratch buffers and streams
+    std::mutex errMu;                   // guards err alone (shard threads report concurrently)
     std::string err;
+    std::atomic<unsigned> nextStart{0}; // host-buffer calls: the shard that takes a call's block 0 rotates from call to call
     DevBuf scratch[2];                  // on the owner device of the last frame call
     int scratchDev = -1;
     hipEvent_t scratchFree[2] = {nullptr, nullptr};
@@ -63,6 +66,7 @@ int mfail(plz4hip_mgpu* m, int code, const char* what, hipError_t e = hipSuccess
         char buf[512];
         if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
         else snprintf(buf, sizeof buf, "%s", what);
+        std::lock_guard<std::mutex> g(m->errMu);
         m->err = buf;
     }
     return code;
@@ -84,16 +88,27 @@ int grow(plz4hip_mgpu* m, int device, DevBuf& b, size_t bytes)
 // blocks of the call that belong to shard k: k, k + G, ...
 inline int shard_blocks(int nBlocks, int G, int k) { return nBlocks > k ? (nBlocks - k + G - 1) / G : 0; }
 
-// run fn(k) for every shard on its own host thread; first failing return code wins
+// run fn(k) for every shard on its own host thread; the first failing shard (lowest k) wins.  Each thread keeps its own error
+// text -- what its ctx reported right after the failing call, on the thread that made it (plz4hip_last_error is per thread) --
+// and the handle's message is set once, after the join.
 template <class F> int per_shard(plz4hip_mgpu* m, F&& fn)
 {
     const int G = (int)m->sh.size();
     std::vector<int> rc((size_t)G, PLZ4HIP_OK);
+    std::vector<std::string> msg((size_t)G);
+    auto run = [&](int k) {
+        rc[(size_t)k] = fn(k);
+        if (rc[(size_t)k] != PLZ4HIP_OK) msg[(size_t)k] = plz4hip_last_error(m->sh[(size_t)k].ctx);
+    };
     std::vector<std::thread> th;
-    for (int k = 1; k < G; ++k) th.emplace_back([&, k]() { rc[(size_t)k] = fn(k); });
-    rc[0] = fn(0);
+    for (int k = 1; k < G; ++k) th.emplace_back(run, k);
+    run(0);
     for (auto& t : th) t.join();
-    for (int k = 0; k < G; ++k) if (rc[(size_t)k] != PLZ4HIP_OK) { m->err = std::string("device ") + std::to_string(m->sh[(size_t)k].device) + ": " + plz4hip_last_error(m->sh[(size_t)k].ctx); return rc[(size_t)k]; }
+    for (int k = 0; k < G; ++k) if (rc[(size_t)k] != PLZ4HIP_OK) {
+        std::lock_guard<std::mutex> g(m->errMu);
+        if (!msg[(size_t)k].empty() || m->err.empty()) m->err = std::string("device ") + std::to_string(m->sh[(size_t)k].device) + ": " + msg[(size_t)k];
+        return rc[(size_t)k];
+    }
     return PLZ4HIP_OK;
 }
 
@@ -154,7 +169,14 @@ void plz4hip_mgpu_destroy(plz4hip_mgpu* m)
 
 int plz4hip_mgpu_count(const plz4hip_mgpu* m) { return m ? (int)m->sh.size() : PLZ4HIP_E_ARG; }
 plz4hip_ctx* plz4hip_mgpu_ctx(plz4hip_mgpu* m, int k) { return (m && k >= 0 && k < (int)m->sh.size()) ? m->sh[(size_t)k].ctx : nullptr; }
-const char* plz4hip_mgpu_last_error(const plz4hip_mgpu* m) { return m ? m->err.c_str() : "null handle"; }
+const char* plz4hip_mgpu_last_error(const plz4hip_mgpu* m)
+{
+    if (!m) return "null handle";
+    static thread_local std::string copy;              // the caller's own copy: valid until this thread asks again
+    std::lock_guard<std::mutex> g(const_cast<plz4hip_mgpu*>(m)->errMu);
+    copy = m->err;
+    return copy.c_str();
+}
 
 // ---------------------------------------------------------------------------------------- host buffers
 // mode 0 encode_records, 1 decode_records, 2 compress_batch, 3 decompress_batch
@@ -163,15 +185,20 @@ static int host_deal(plz4hip_mgpu* m, int mode, int nBlocks, const void* const* 
 {
     if (!m || nBlocks < 0 || (nBlocks && (!in || !inLen || !out || !result))) return mfail(m, PLZ4HIP_E_ARG, "plz4hip_mgpu: bad argument");
     if (nBlocks == 0) return PLZ4HIP_OK;
-    std::lock_guard<std::mutex> g(m->mu);
+    // No handle-wide lock: every ctx serialises its own calls, so concurrent callers (the reference's worker goroutines each call
+    // Compress for one block, async/writer.go:232-282) only wait for each other per device.  The deal starts at a shard that
+    // rotates from call to call -- block i of this call goes to shard (start + i) mod G -- so that a stream of one-block calls
+    // uses every GPU instead of queueing on device 0.  Results land in the caller's arrays in block order either way.
     const int G = (int)m->sh.size();
-    return per_shard(m, [&](int k) -> int {
+    const int start = (int)(m->nextStart.fetch_add((unsigned)(nBlocks < G ? nBlocks : G)) % (unsigned)G);
+    return per_shard(m, [&](int sk) -> int {
+        const int k = (sk - start + G) % G;                     // this shard takes blocks k, k + G, ... of the call
         const int nb = shard_blocks(nBlocks, G, k);
         if (!nb) return PLZ4HIP_OK;
         std::vector<const void*> i2((size_t)nb); std::vector<void*> o2((size_t)nb);
         std::vector<int32_t> l2((size_t)nb), c2((size_t)nb), r2((size_t)nb), s2((size_t)nb);
         for (int j = 0; j < nb; ++j) { const int i = k + j * G; i2[(size_t)j] = in[i]; l2[(size_t)j] = inLen[i]; o2[(size_t)j] = out[i]; if (outCap) c2[(size_t)j] = outCap[i]; }
-        plz4hip_ctx* c = m->sh[(size_t)k].ctx;
+        plz4hip_ctx* c = m->sh[(size_t)sk].ctx;
         int rc;
         switch (mode) {
         case 0:  rc = plz4hip_encode_records(c, nb, i2.data(), l2.data(), bsz, level, blockChecksum, o2.data(), r2.data()); break;
@@ -313,6 +340,12 @@ int plz4hip_mgpu_dev_decode_frame(plz4hip_mgpu* m, int nBlocks, int owner, const
     const int G = (int)m->sh.size();
     if (owner < 0 || owner >= G) return mfail(m, PLZ4HIP_E_ARG, "plz4hip_mgpu_dev_decode_frame: owner");
     if (nBlocks == 0) return PLZ4HIP_OK;
+    // the offsets come from a frame index that may be damaged: every record is its size word + at most bsz bytes (+ checksum)
+    if (recOff[0] < 0) return mfail(m, PLZ4HIP_E_ARG, "plz4hip_mgpu_dev_decode_frame: recOff[0] < 0");
+    for (int i = 0; i < nBlocks; ++i) {
+        const int64_t l = recOff[i + 1] - recOff[i];
+        if (l < 4 || l > (int64_t)bsz + 8) return mfail(m, PLZ4HIP_E_ARG, "plz4hip_mgpu_dev_decode_frame: recOff is not a list of records (length outside 4..bsz+8)");
+    }
     std::lock_guard<std::mutex> g(m->mu);
     Shard& o = m->sh[(size_t)owner];
     // 1. deal the records: shard k's records are packed on the owner (record mover), then copied to device k in one go

@@ -74,6 +74,18 @@ def test_gpu_encode_4m(orc, eng, kind):
     _check_encode(orc, eng, srcs[:1], [orc.bound(bsz)])         # block API: cap == bound (plz4_block.go:105)
 
 
+def test_gpu_encode_4m_against_the_reference_itself(ref, orc, eng):
+    """The level-1 GPU tests above compare with the oracle restatement (itself pinned to the reference on the CPU); here one 4 MiB
+    T and one M block go against LZ4_compress_fast of oracle/_ref directly, at both capacities plz4 uses."""
+    bsz = 4 << 20
+    srcs = [synth.make("T", bsz, bsz), synth.make("M", 2 * bsz, bsz)[bsz:]]
+    for cap in (bsz, orc.bound(bsz)):
+        res, outs = eng.compress_batch(srcs, [cap] * len(srcs))
+        for s, r, o in zip(srcs, res, outs):
+            n, want = ref.compress_fast(s, cap)
+            assert int(r) == n and np.array_equal(o, want[:n]), (cap, int(r), n)
+
+
 def test_gpu_encode_over_4m(orc, eng):
     """Blocks above 4 MiB (raw block API only) run the table without tags."""
     src = synth.text((5 << 20) + 123, seed=9)
@@ -199,6 +211,28 @@ def test_gpu_records(orc, eng, bsz, checksum):
     assert int(st[0]) == 2                                       # PLZ4HIP_BLK_SIZE_OVERFLOW
 
 
+def test_gpu_records_that_inflate_past_the_block_size(ref, orc, eng):
+    """The reference decodes a block into the whole pooled buffer, bsz + 8 bytes (blk/pool.go:23-26, blk/blk.go:51-53): a block that
+    inflates to bsz + 1 .. bsz + 8 bytes is ACCEPTED, bsz + 9 is liblz4's output-overflow error.  Same here, same codes."""
+    bsz = 64 << 10
+    base = synth.text(bsz + 64, seed=3)
+    recs, wants = [], []
+    for extra in (0, 1, 7, 8, 9, 16):
+        plain = np.ascontiguousarray(base[:bsz + extra])
+        n, comp = ref.compress_fast(plain, orc.bound(plain.size))
+        assert 0 < n <= bsz                                              # (a size word above bsz is a different error)
+        rec = np.concatenate([np.frombuffer(np.uint32(n).tobytes(), dtype=np.uint8), comp[:n]])
+        recs.append(np.ascontiguousarray(rec))
+        wants.append((plain, ref.decompress_safe(np.ascontiguousarray(comp[:n]), bsz + 8)[0]))
+    res, st, outs = eng.decode_records(recs, bsz, False)
+    for (plain, code), r, k, o, extra in zip(wants, res, st, outs, (0, 1, 7, 8, 9, 16)):
+        assert int(r) == code, (extra, int(r), code)
+        if extra <= 8:
+            assert int(k) == 0 and code == plain.size and np.array_equal(o, plain), extra
+        else:
+            assert code < 0 and int(k) != 0, (extra, code, int(k))
+
+
 def test_gpu_dev_pipeline(orc, eng):
     """Device-resident encode -> scan -> compaction gives exactly the oracle frame's block section, and the
     device decoder restores the plaintext (config 2 / config 3 plumbing at a size the oracle handles quickly)."""
@@ -292,8 +326,39 @@ def test_gpu_dev_compress_levels_and_trim(ref, orc):
             assert int(res[i]) == want_n and np.array_equal(out[i * stride:i * stride + want_n], want[:want_n]), (lvl, i)
         if lvl == 5:
             e.trim()                                                             # HC workspace gone; the next call allocates again
+    # an understated maxLen: the lengths live on the device and the workspaces are sized from maxLen, so a block longer than that
+    # must not be touched -- its result is PLZ4HIP_E_ARG, its neighbours are unaffected (every level's kernels)
+    for lvl in (1, 5, 12):
+        d_dst = torch.zeros(len(srcs) * stride, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(len(srcs), dtype=torch.int32, device=dev)
+        e._chk(e.L.plz4hip_dev_compress(e.h, len(srcs), d_src.data_ptr(), stride, d_len.data_ptr(), d_dst.data_ptr(), stride,
+                                        d_cap.data_ptr(), lvl, 8192, d_res.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        res = d_res.cpu().numpy(); out = d_dst.cpu().numpy()
+        assert [int(r) for r in res[:3]] == [-1, -1, -1], (lvl, res)             # PLZ4HIP_E_ARG
+        want_n, want = (orc.compress_fast(srcs[3], cap) if lvl == 1 else ref.compress_hc(srcs[3], cap, lvl))
+        assert int(res[3]) == want_n and np.array_equal(out[3 * stride:3 * stride + want_n], want[:want_n]), lvl
     recs = e.encode_records(srcs, 1 << 19, True)
     e.trim()
     recs2 = e.encode_records(srcs, 1 << 19, True)
     assert all(np.array_equal(a, b) for a, b in zip(recs, recs2))
     e.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bench_modes_run_on_one_gpu():
+    """bench.py's other code paths on the one GPU of the box: the N > 1 path (process group, gather stream, size all-gather,
+    interleave on rank 0) with a single rank (PLZ4_BENCH_FORCE_GATHER), and the decode-only mode of configs[2]."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PLZ4_BENCH_FORCE_GATHER="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--blocks", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "frame_gather" in line["ms"]
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--blocks", "64", "--steps", "1", "--warmup", "1", "--decode-only"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "configs[2]" in line["config"]["workload"] and line["value"] > 0 and line["roofline"]["kernel"] == "k_decode_rec"

@@ -134,10 +134,10 @@ def test_gpu_hc_config4_full_size(ref, orc):
         res, st, outs = eng.decode_records([np.ascontiguousarray(r) for r in recs], bsz, True)
         for s, r, k, o in zip(srcs, res, st, outs):
             assert int(k) == 0 and int(r) == s.size and np.array_equal(o, s)
-    # levels 7, 10 and 11 have no committed 4 MiB digest: a T and the M block against the reference run here (the searches on the
-    # per-hash lists, 10 and 11 with the chain swap)
+    # the levels without a committed 4 MiB digest: a T and the M block against the reference run here (level 3 on the chain
+    # alone, the others on the per-hash lists, 10 and 11 with the chain swap)
     tblk = synth.make("T", bsz, bsz)
-    for lvl in (7, 10, 11):
+    for lvl in (3, 4, 6, 7, 8, 10, 11):
         recs = eng.encode_records([tblk, mblk], bsz, True, level=lvl)
         for blk, rec in zip((tblk, mblk), recs):
             n, want = ref.compress_hc(blk, bsz, lvl)
