@@ -35,8 +35,8 @@ for rep in range(2):
     nb = max(v["blocks"], 1); g = max(v["batch"], 1)
     print("B=%d  %.1f ms  -> %.1f MiB/s (instrumented)" % (B, dt * 1e3, B * 4 / dt))
     print("   per block: batches %.0f primes %.1f generic %.1f repairs %.0f seqs %.0f cycles %.3e" % (v["batch"] / nb, v["prime"] / nb, v["generic"] / nb, v["repair"] / nb, v["seq"] / nb, v["cyc_total"] / nb))
-    print("   per grid batch (cycles): mem-wait %.0f | peek+commit+LDS %.0f | refresh %.0f | compare+requests %.0f | walk %.0f | store+state+patch %.0f | sum %.0f"
+    print("   per grid batch (cycles): memory wait %.0f | peek + compare %.0f | [commit + verify + gather + compare %.0f, inside the rounds] | requests %.0f | rounds (walk, commit, verify; second rounds) %.0f | records + state %.0f | sum of the outer sections %.0f"
           % (v["cyc_mem"] / g, v["cyc_lds"] / g, v["cyc_refresh"] / g, v["cyc_cmp"] / g, v["cyc_walk"] / g, v["cyc_tail"] / g,
-             (v["cyc_mem"] + v["cyc_lds"] + v["cyc_refresh"] + v["cyc_cmp"] + v["cyc_walk"] + v["cyc_tail"]) / g))
-    print("   walk split: nextHit+start %.0f | hops %.0f (%.1f hop slots) | executed lanes + checks %.0f | general loop %.0f (taken by %.1f%% of the batches)"
-          % (v["cyc_nh"] / g, v["cyc_hop"] / g, v["hops"] / g, v["cyc_e"] / g, v["cyc_slow"] / g, 100.0 * v["repair"] / g))
+             (v["cyc_mem"] + v["cyc_lds"] + v["cyc_cmp"] + v["cyc_walk"] + v["cyc_tail"]) / g))
+    print("   inside the rounds: hops %.0f (%.1f hop slots) | executed lanes %.0f | batches that took a second round %.1f%%"
+          % (v["cyc_hop"] / g, v["hops"] / g, v["cyc_e"] / g, 100.0 * v["repair"] / g))
