@@ -25,12 +25,14 @@
 #define STAT_DECL    unsigned long long st_[24] = {0}
 #define STAT_NOW()   ((unsigned long long)__builtin_readcyclecounter())
 #define STAT_FLUSH() do { if (LANE == 0) for (int i_ = 0; i_ < 24; ++i_) atomicAdd(&plz4_stats[i_], st_[i_]); } while (0)
+#define STAT_PTR     st_
 extern __device__ unsigned long long plz4_stats[24];
 #else
 #define STAT(i, v)   do {} while (0)
 #define STAT_DECL    do {} while (0)
 #define STAT_NOW()   0ull
 #define STAT_FLUSH() do {} while (0)
+#define STAT_PTR     nullptr
 #endif
 enum { S_GRID = 0, S_GENERIC, S_MISORDER, S_SEQ_GRID, S_SEQ_GEN, S_TWINSTOP, S_SAT, S_LONGBACK, S_MEMLIT, S_WALKITER,
        S_CYC_TOTAL, S_CYC_LOAD, S_CYC_WALK, S_CYC_FIX, S_CYC_GEN, S_CYC_SAT, S_CYC_MEMLIT, S_BLOCKS, S_LANES_EXEC,
@@ -1253,12 +1255,15 @@ DEV int64_t read_more_len(const uint8_t* src, int* ip, int ilimit, bool initialC
 // kLds: the batch's output is assembled in `lb`, kDecLdsBytes of LDS owned by this wave (the last kDecTail bytes already
 // written, then up to 1024 new ones), and stored to memory in one coalesced sweep.  Near matches then read LDS instead of
 // waiting a memory round trip per dependency round; `tailAt` is the output position the LDS tail is valid for.
-enum : int { kDecTail = 32, kDecLdsBytes = kDecTail + 1024 + 64 };
+enum : int { kDecTail = 32, kDecDump = kDecTail + 1024 + 64, kDecLdsBytes = kDecDump + 16 };    // (kDecDump: 16 bytes nobody reads)
 template <bool kLds>
 DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int* ipp, int64_t* opp,
-                                LVREF(v16u_t, win), int* winIp, uint8_t* lb = nullptr, int64_t* tailAt = nullptr)
+                                LVREF(v16u_t, win), int* winIp, uint8_t* lb = nullptr, int64_t* tailAt = nullptr,
+                                unsigned long long* st_ = nullptr)           // (diagnostics build: the caller's counters)
 {
     const int ip0 = *ipp; const int64_t op0 = *opp;
+    (void)st_;
+    const unsigned long long td0 = STAT_NOW(); (void)td0;
     // every lane holds the 16 input bytes from its window position on; normally requested by the previous batch
     if (*winIp != ip0) { LANES({ win[I_] = *(const v16u_t*)(src + ip0 + LANE); }) }
     LV(uint32_t, b0); LV(int, ll); LV(int, ml); LV(int, off); LV(int, nxt); LV(int, outLen); LV(int, plain); LV(int, coop);
@@ -1320,19 +1325,25 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         })
     }
     const uint64_t plainMask = BALLOT(plain[I_]);
+    const unsigned long long td1 = STAT_NOW(); (void)td1;
+    STAT(0, td1 - td0);
     if (!(plainMask & 1)) return 0;
     // Follow the token chain through the whole window, four hops to a branch (mark the lane, fetch its successor; a
     // finished walk only re-marks lane 0, where it started), then cut the chain at the first sequence that is not plain.
     uint64_t members = 0;
     {
-        int cur = 0;
+        // (successors clamped to 64 per lane up front: the hop's & 63 then reads a finished walk back as lane 0, where the chain
+        // started -- walking on from there only re-marks its own members, so the hop needs no test; `seen` remembers the end)
+        LV(int, nxtC);
+        LANES({ nxtC[I_] = min_(nxt[I_], 64); })
+        int cur = 0, seen = 0;
         do {
             for (int u = 0; u < 4; ++u) {
-                const int n1 = RL(nxt, cur & 63);
                 members |= 1ull << (cur & 63);
-                cur = (cur < 64) ? min_(n1, 64) : 64;
+                cur = RL(nxtC, cur & 63);
+                seen |= cur;
             }
-        } while (cur < 64);
+        } while (seen < 64);
         const uint64_t odd = members & ~plainMask;
         if (odd) members &= (1ull << ctz64(odd)) - 1;
     }
@@ -1354,6 +1365,8 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
                                      (kLds && coop[I_] && sp[I_] < op0 - kDecTail && (int64_t)sp[I_] + ml[I_] > op0)));
         if (stop) members &= (1ull << ctz64(stop)) - 1;
     }
+    const unsigned long long td2 = STAT_NOW(); (void)td2;
+    STAT(1, td2 - td1);
     if (!members) return 0;
     const uint64_t mL = members;
     const int last = 63 - __builtin_clzll(members);
@@ -1367,15 +1380,23 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
     const uint64_t far = mL & ~coopM & BALLOT((int64_t)sp[I_] + ml[I_] <= op0);
     if (kLds) {
         const int total = RL(acc, last);                       // bytes this batch produces
-        auto put_match = [&](uint8_t* d, const v16u_t& a, uint32_t b, int rem) {
+        // `rem` (4..18) bytes of (a, b) to d, for the lanes that are `on` -- without a branch: five stores per lane, each to its
+        // place or, when it has nothing to write, to the dump bytes behind the buffer (a divergent `if` costs this machine
+        // ~45 cycles whether any lane takes it or not, a redirected store costs a select)
+        auto put_match = [&](uint8_t* d, const v16u_t& a, uint32_t b, int rem, bool on) {
+            uint8_t* const dump = lb + kDecDump;
             const uint64_t lo = (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), hi = (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32);
-            uint64_t cur;
-            if (rem >= 16)     { st64u(d, lo); st64u(d + 8, hi); d += 16; rem -= 16; cur = b; }
-            else if (rem >= 8) { st64u(d, lo); d += 8; rem -= 8; cur = hi; }
-            else cur = lo;
-            if (rem & 4) { st32u(d, (uint32_t)cur); d += 4; cur >>= 32; }
-            if (rem & 2) { st16u(d, (uint16_t)cur); d += 2; cur >>= 16; }
-            if (rem & 1) { *d = (uint8_t)cur; }
+            const bool c16 = on & (rem >= 16), c8 = on & ((rem & 8) != 0);
+            st64u((c16 | c8) ? d : dump, lo);
+            st64u(c16 ? d + 8 : dump, hi);
+            uint64_t cur = c16 ? (uint64_t)b : (c8 ? hi : lo);
+            uint8_t* e = d + (c16 ? 16 : 0) + (c8 ? 8 : 0);
+            const bool c4 = on & ((rem & 4) != 0), c2 = on & ((rem & 2) != 0), c1 = on & ((rem & 1) != 0);
+            st32u(c4 ? e : dump, (uint32_t)cur);
+            e += c4 ? 4 : 0; cur = c4 ? (cur >> 32) : cur;
+            st16u(c2 ? e : dump, (uint16_t)cur);
+            e += c2 ? 2 : 0; cur = c2 ? (cur >> 16) : cur;
+            *(c1 ? e : dump) = (uint8_t)cur;
         };
         // far matches: their bytes are requested from memory first ...
         LV(v16u_t, fa); LV(uint32_t, fb);
@@ -1395,7 +1416,11 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
             const int lm = lp & 0xFFFF, m1 = m + (lp >> 16);              // m1: the byte before the first literal
             if (upto && LANE > m1 && LANE <= m1 + lm) lb[kDecTail + (os - (int)op0) + (LANE - m1 - 1)] = (uint8_t)b0[I_];
         })
-        LANES({ if ((far >> LANE) & 1) put_match(lb + kDecTail + (outStart[I_] - (int)op0) + (ll[I_] & 0xFFFF), fa[I_], fb[I_], ml[I_]); })
+        const unsigned long long td3 = STAT_NOW(); (void)td3;
+        STAT(2, td3 - td2);
+        LANES({ put_match(lb + kDecTail + (outStart[I_] - (int)op0) + (ll[I_] & 0xFFFF), fa[I_], fb[I_], ml[I_], (far >> LANE) & 1); })
+        const unsigned long long td4 = STAT_NOW(); (void)td4;
+        STAT(3, td4 - td3);
         // the rest in dependency order, LDS to LDS (see the memory version below for the rule)
         for (uint64_t pend = mL & ~far; pend; ) {
             const int f  = ctz64(pend);
@@ -1407,6 +1432,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
                 else wave_copy_match(lb, kDecTail + lo, RL(off, f), len);
                 pend &= pend - 1;
             } else {
+                STAT(8, 1);
                 const uint64_t go = pend & ~coopM & BALLOT(sp[I_] + ml[I_] - (int)op0 <= lo);
                 LANES({
                     if ((go >> LANE) & 1) {
@@ -1417,28 +1443,31 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
                     }
                 })
                 LDS_FENCE();
-                LANES({ if ((go >> LANE) & 1) put_match(lb + kDecTail + (outStart[I_] - (int)op0) + (ll[I_] & 0xFFFF), fa[I_], fb[I_], ml[I_]); })
+                LANES({ put_match(lb + kDecTail + (outStart[I_] - (int)op0) + (ll[I_] & 0xFFFF), fa[I_], fb[I_], ml[I_], (go >> LANE) & 1); })
                 pend &= ~go;
             }
         }
         LDS_FENCE();
-        // one sweep to memory: 16 bytes per lane, then the odd bytes; and keep the last kDecTail bytes for the next batch
+        const unsigned long long td5 = STAT_NOW(); (void)td5;
+        STAT(4, td5 - td4); STAT(6, 1);
+        // one sweep to memory, 16 bytes per lane (total <= 1024); the last chunk is written whole -- the bytes behind `total` are
+        // the next batch's (or the sequential step's) to write, and the caller has checked that 1088 bytes of room are left --
+        // and the last kDecTail bytes are kept for the next batch: all LDS reads first, one wait, then the stores
+        LV(v16u_t, sw); LV(uint32_t, t8);
         LANES({
-            for (int cpos = LANE * 16; cpos + 16 <= total; cpos += 1024) {
-                v16u_t a; const uint64_t q0 = ld64u(lb + kDecTail + cpos), q1 = ld64u(lb + kDecTail + cpos + 8);
-                a.w[0] = (uint32_t)q0; a.w[1] = (uint32_t)(q0 >> 32); a.w[2] = (uint32_t)q1; a.w[3] = (uint32_t)(q1 >> 32);
-                *(v16u_t*)(dst + op0 + cpos) = a;
-            }
-            const int odd0 = total & ~15;
-            if (LANE < 16 && odd0 + LANE < total) dst[op0 + odd0 + LANE] = lb[kDecTail + odd0 + LANE];
+            const uint64_t q0 = ld64u(lb + kDecTail + LANE * 16), q1 = ld64u(lb + kDecTail + LANE * 16 + 8);
+            sw[I_].w[0] = (uint32_t)q0; sw[I_].w[1] = (uint32_t)(q0 >> 32); sw[I_].w[2] = (uint32_t)q1; sw[I_].w[3] = (uint32_t)(q1 >> 32);
+            t8[I_] = (uint32_t)lb[total + (LANE & (kDecTail - 1))];
         })
-        LV(uint32_t, t8);
-        LANES({ t8[I_] = (LANE < kDecTail) ? (uint32_t)lb[total + LANE] : 0u; })
         LDS_FENCE();
-        LANES({ if (LANE < kDecTail) lb[LANE] = (uint8_t)t8[I_]; })
+        LANES({
+            if (LANE * 16 < total) *(v16u_t*)(dst + op0 + LANE * 16) = sw[I_];
+            if (LANE < kDecTail) lb[LANE] = (uint8_t)t8[I_];
+        })
         *tailAt = op0 + total;
         *ipp = ipn;
         *opp = op0 + total;
+        STAT(5, STAT_NOW() - td5); STAT(7, __builtin_popcountll(far));
         return __builtin_popcountll(members);
     }
     auto copy_matches = [&](const uint64_t who) {
@@ -1517,7 +1546,7 @@ DEV int wave_decode_block(const uint8_t* __restrict__ src, const int n, uint8_t*
     for (;;) {
         if (fast && ip + 160 <= iend && op + 1088 <= oend) {
             WAVE_FENCE();
-            const int nm = wave_decode_plain_batch<kLds>(src, dst, &ip, &op, win, &winIp, lb, &tailAt);
+            const int nm = wave_decode_plain_batch<kLds>(src, dst, &ip, &op, win, &winIp, lb, &tailAt, STAT_PTR);
             STAT(S_DBATCH, 1); STAT(S_DMEMB, nm);
             if (nm > 0) { WAVE_FENCE(); continue; }
         }

@@ -358,7 +358,10 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 const bool any = w < 64;
                 uint64_t m = 0;
                 const unsigned long long tw1 = STAT_NOW(); (void)tw1;
-                for (int u = 0; u < 8; ++u) {
+#if !defined(PLZ4_FAST_HOPS)
+#define PLZ4_FAST_HOPS 6
+#endif
+                for (int u = 0; u < PLZ4_FAST_HOPS; ++u) {
                     const int n1 = RL(nextHit, w & 63);
                     m |= 1ull << (w & 63);
                     w = (w < 64) ? n1 : 64;
