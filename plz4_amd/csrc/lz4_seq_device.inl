@@ -199,13 +199,12 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
             const unsigned long long ts2 = STAT_NOW(); (void)ts2;
             STAT(P_CYC_LDS, ts2 - ts1);
             // ---- 3. requests for the batches to come: the peeked candidates of batch k+1 (every lane loads: its candidate, or
-            // its own position when it has none), the window of batch k+2 into registers batch k-1 is done with (its C: its P
-            // still serves this batch; they change places at the end)
+            // its own position when it has none), the window of batch k+2 into the stage batch k-1 is done with
             LANES({
                 const uint32_t q1 = (uint32_t)(base + 64 + LANE), pr = next[I_].pk >> sh;
                 const bool pc = (pr < q1) & (pr + kMaxDist >= q1) & (((next[I_].pk ^ next[I_].ent) & tagMask) == 0);
                 next[I_].C = load_win20(src, (int)(pc ? pr : q1));
-                prev[I_].C = load_win20(src, base + 128 + LANE);
+                prev[I_].P = load_win20(src, base + 128 + LANE);
             })
             const unsigned long long ts3 = STAT_NOW(); (void)ts3;
             STAT(P_CYC_CMP, ts3 - ts2);
@@ -408,16 +407,16 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 // (ascending lane order of the atomics on one slot is what makes the returned entry the sequential one: any other
                 // order shows up as a position at or above the lane's own)
                 const uint64_t misorder = EL & BALLOT((rent[I_] >> sh) >= (uint32_t)(base + LANE));
-                const uint64_t noRegs   = upd & BALLOT(rent[I_] != cur[I_].pk && (rent[I_] >> sh) + 64u < (uint32_t)base);
+                const uint64_t noRegs   = upd & BALLOT(rent[I_] != cur[I_].pk && (rent[I_] >> sh) < (uint32_t)base);
                 LV(bool, hitN); LV(int, fwdN); LV(Win20, Wn);
                 LANES({
                     const bool u = (upd >> LANE) & 1;
                     ce[I_] = u ? rent[I_] : ce[I_];
-                    const int t = (int)(ce[I_] >> sh) - base;               // (& 63: the lane in either batch)
+                    const int t = (int)(ce[I_] >> sh) - base;               // the lane of this batch whose position that is
                     const bool same = ce[I_] == cur[I_].pk;
                     for (int k = 0; k < 5; ++k) {
-                        const uint32_t a = SHFLF(cur, P.w[k], t), b = SHFLF(prev, P.w[k], t);
-                        Wn[I_].w[k] = same ? cur[I_].C.w[k] : (t >= 0 ? a : b);
+                        const uint32_t a = SHFLF(cur, P.w[k], t);
+                        Wn[I_].w[k] = same ? cur[I_].C.w[k] : a;
                     }
                 })
                 compare(Wn, hitN, fwdN);
@@ -457,14 +456,14 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                         const uint64_t upd2 = probes & BALLOT(rent[I_] != ce[I_]);
                         if (EL2 & BALLOT((rent[I_] >> sh) >= (uint32_t)(base + LANE))) { EMU_CNT(2, 1); giveUp = true; break; }
                         if (!upd2) break;                                      // every probe read what it had assumed
-                        if (upd2 & BALLOT(rent[I_] != cur[I_].pk && (rent[I_] >> sh) + 64u < (uint32_t)base)) { EMU_CNT(7, 1); giveUp = true; break; }
+                        if (upd2 & BALLOT(rent[I_] != cur[I_].pk && (rent[I_] >> sh) < (uint32_t)base)) { EMU_CNT(7, 1); giveUp = true; break; }
                         LANES({
                             if ((upd2 >> LANE) & 1) ce[I_] = rent[I_];
                             const int t = (int)(ce[I_] >> sh) - base;
                             const bool same = ce[I_] == cur[I_].pk;
                             for (int k = 0; k < 5; ++k) {
-                                const uint32_t a = SHFLF(cur, P.w[k], t), b = SHFLF(prev, P.w[k], t);
-                                Wn[I_].w[k] = same ? cur[I_].C.w[k] : (t >= 0 ? a : b);
+                                const uint32_t a = SHFLF(cur, P.w[k], t);
+                                Wn[I_].w[k] = same ? cur[I_].C.w[k] : a;
                             }
                         })
                         compare(Wn, hitN, fwdN);
@@ -482,6 +481,20 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 LDS_FENCE();
                 return kGridGeneric;
             }
+            // ---- 4b. batch k+1's slots once more: the table holds this batch's inserts now, and a slot that changed since the peek
+            // was taken by an executed lane of THIS batch -- whose window is here.  Its bytes replace the requested ones, so the
+            // next batch starts from candidates that are exact against everything before it; what its commit can still return
+            // differently is a lane of its own.
+            LANES({
+                const uint32_t late = T[next[I_].h];
+                const bool ch = late != next[I_].pk;
+                const int t = (int)(late >> sh) - base;
+                for (int k = 0; k < 5; ++k) {
+                    const uint32_t x = SHFLF(cur, P.w[k], t);
+                    next[I_].C.w[k] = ch ? x : next[I_].C.w[k];
+                }
+                next[I_].pk = late;
+            })
             const unsigned long long ts5 = STAT_NOW(); (void)ts5;
             STAT(P_CYC_WALK, ts5 - ts3);
 
@@ -511,7 +524,6 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 sBase = sB; sIter = sI; hasRe = nRe; rePos = nRp;
             }
             width = 64;
-            LANES({ prev[I_].P = prev[I_].C; })                            // the window of batch k+2 takes its place
             STAT(P_CYC_TAIL, STAT_NOW() - ts5);
             return kGridNext;
         };
