@@ -409,23 +409,29 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 const uint64_t misorder = EL & BALLOT((rent[I_] >> sh) >= (uint32_t)(base + LANE));
                 const uint64_t noRegs   = upd & BALLOT(rent[I_] != cur[I_].pk && (rent[I_] >> sh) < (uint32_t)base);
                 LV(bool, hitN); LV(int, fwdN); LV(Win20, Wn);
-                LANES({
-                    const bool u = (upd >> LANE) & 1;
-                    ce[I_] = u ? rent[I_] : ce[I_];
-                    const int t = (int)(ce[I_] >> sh) - base;               // the lane of this batch whose position that is
-                    const bool same = ce[I_] == cur[I_].pk;
-                    for (int k = 0; k < 5; ++k) {
-                        const uint32_t a = SHFLF(cur, P.w[k], t);
-                        Wn[I_].w[k] = same ? cur[I_].C.w[k] : a;
-                    }
-                })
-                compare(Wn, hitN, fwdN);
-                // (a window that compares equal to its end says nothing about the length behind it: that one is measured again)
-                const uint64_t diff = upd & BALLOT((hitN[I_] != hit[I_]) | (fwdN[I_] != fwd[I_]) | (fwdN[I_] == 16));
-                LANES({
-                    const bool u = (upd >> LANE) & 1;
-                    hit[I_] = u ? hitN[I_] : hit[I_]; fwd[I_] = u ? fwdN[I_] : fwd[I_]; eLane[I_] = LANE + kMinMatch + fwd[I_];
-                })
+                uint64_t diff = 0;
+#if !defined(PLZ4_VERIFY_ALWAYS)
+                if (upd)                     // (about half of the batches on text: worth the one conditional)
+#endif
+                {
+                    LANES({
+                        const bool u = (upd >> LANE) & 1;
+                        ce[I_] = u ? rent[I_] : ce[I_];
+                        const int t = (int)(ce[I_] >> sh) - base;               // the lane of this batch whose position that is
+                        const bool same = ce[I_] == cur[I_].pk;
+                        for (int k = 0; k < 5; ++k) {
+                            const uint32_t a = SHFLF(cur, P.w[k], t);
+                            Wn[I_].w[k] = same ? cur[I_].C.w[k] : a;
+                        }
+                    })
+                    compare(Wn, hitN, fwdN);
+                    // (a window that compares equal to its end says nothing about the length behind it: that one is measured again)
+                    diff = upd & BALLOT((hitN[I_] != hit[I_]) | (fwdN[I_] != fwd[I_]) | (fwdN[I_] == 16));
+                    LANES({
+                        const bool u = (upd >> LANE) & 1;
+                        hit[I_] = u ? hitN[I_] : hit[I_]; fwd[I_] = u ? fwdN[I_] : fwd[I_]; eLane[I_] = LANE + kMinMatch + fwd[I_];
+                    })
+                }
                 STAT(P_CYC_REFRESH, STAT_NOW() - tc0);
                 EMU_CNT(5, upd != 0);
                 const uint64_t trouble = misorder | noRegs | diff | (mm & special1);
