@@ -97,7 +97,8 @@ DEV int win20_fwd(const Win20& p, const Win20& c)
 // by unrolling (grid(S2,S0,S1), grid(S0,S1,S2), grid(S1,S2,S0)), not by copies.
 #if defined(PLZ4_EMU)
 #define SHFLF(x, f, l) ((x)[(l) & 63].f)
-unsigned long long plz4_emu_cnt[8]; unsigned long long plz4_emu_deep[4];               // test diagnostics: grid batches, cold starts, lanes reloaded from memory, twin repairs
+unsigned long long plz4_emu_cnt[8];               // test diagnostics: [0] grid batches, [1] primes, [2] atomics out of order, [4] long matches measured, [5] batches whose commit
+                                                  // returned another entry to a probe, [6] batches with a second round, [7] entries outside the registers
 #define EMU_CNT(i, v) (plz4_emu_cnt[(i)] += (unsigned long long)(v))
 #else
 #define SHFLF(x, f, l) plz4_bpermute((x)[0].f, (l))
@@ -286,64 +287,6 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
             // touches bit 0 again), more only if the batch has more matches; matches longer than the speculative window are
             // taken at that length and reported by the caller's check (a uniform branch costs this machine 80-90 cycles, taken
             // or not: scripts/micro/branch.hip -- the steady state is written to have a handful of them per batch, not forty)
-#if defined(PLZ4_WALK_SCALAR_E)
-            auto walk_fast = [&](const uint64_t hits) {
-                // per lane: the first recorded match at or after the end of the match that starts here (64: none), and how many
-                // lanes behind it that match covers.  Lane 0 is made the walk's sink: successor 64 (read back as lane 0 by the
-                // hop's & 63), covers nothing -- so a hop past the end changes nothing and needs no test.  A walk that really
-                // starts at lane 0 takes its first hop by hand.
-                LV(int, nextHit); LV(int, covN);
-                LANES({
-                    const uint64_t ah = (eLane[I_] < 64) ? (hits >> eLane[I_]) : 0;
-                    nextHit[I_] = ah ? eLane[I_] + ctz64(ah) : 64;
-                    covN[I_] = fwd[I_] + (kMinMatch - 1);               // lanes LANE+1 .. eLane-1
-                })
-                const uint64_t hm = (cur0 < 64) ? (hits & (~0ull << (cur0 & 63))) : 0;
-                int w0 = hm ? ctz64(hm) : 64;
-                w0 = (w0 > lim0) ? 64 : w0;                            // (the stride limit concerns the first match only)
-                const bool first0 = (w0 == 0);
-                const int n0 = RL(nextHit, 0), c0 = RL(covN, 0);
-                LANES({ nextHit[I_] = (LANE == 0) ? 64 : nextHit[I_]; covN[I_] = (LANE == 0) ? 0 : covN[I_]; })
-                int w = first0 ? n0 : w0;
-                uint64_t m = 0;
-                uint64_t cov = first0 ? (((1ull << (c0 & 63)) - 1ull) << 1) : 0;     // (a first match at lane 0 covers c0 <= 19 lanes)
-                const unsigned long long tw1 = STAT_NOW(); (void)tw1;
-                for (int u = 0; u < 8; ++u) {
-                    const int n1 = RL(nextHit, w & 63), cw = RL(covN, w & 63);
-                    m   |= 1ull << (w & 63);
-                    cov |= BFM64(cw, w & 63) << 1;                       // lanes w+1 .. w+cw (a match at lane 63 covers nothing here)
-                    w = n1;
-                }
-                while (w < 64) {
-                    for (int u = 0; u < 4; ++u) {
-                        const int n1 = RL(nextHit, w & 63), cw = RL(covN, w & 63);
-                        m   |= 1ull << (w & 63);
-                        cov |= BFM64(cw, w & 63) << 1;                       // lanes w+1 .. w+cw (a match at lane 63 covers nothing here)
-                        w = n1;
-                    }
-                }
-                STAT(P_HOPS, 8);
-                mm = (m & ~1ull) | (first0 ? 1ull : 0ull);
-                eL = RL(eLane, (63 - __builtin_clzll(mm | 1ull)) & 63);
-                eL = mm ? eL : 0;
-                finished = false;
-                const unsigned long long tw2 = STAT_NOW(); (void)tw2;
-                STAT(P_CYC_HOP, tw2 - tw1);
-                // the executed lanes, in scalar arithmetic: probes = the lanes from the first probe on that no executed match
-                // covers (a match's own first lane is a probe); the ip-2 insert of a match (lz4.c:1236-1242) is the last but one
-                // lane it covers -- matches are at least 4 long and a covered run ends where its match ends, except the last
-                // one, which may run past lane 63
-                Send = mm ? 64 : min_(64, lim0 + 1);
-                const uint64_t from = (cur0 < 64) ? (~0ull << (cur0 & 63)) : 0;
-                const uint64_t upto = (Send >= 64) ? ~0ull : ((1ull << (Send & 63)) - 1ull);
-                probes = ~cov & from & upto;
-                uint64_t ins = (cov & ~(cov >> 1)) >> 1;               // a run's last lane, one down
-                ins = (eL >= 65) ? (ins & ~(1ull << 62)) : ins;        // the last run is cut off by the batch, not ended ...
-                ins = (eL == 65) ? (ins | (1ull << 63)) : ins;         // ... and ends one lane behind it
-                E = probes | ins | insBit0;
-                STAT(P_CYC_E, STAT_NOW() - tw2);
-            };
-#else
             auto walk_fast = [&](const uint64_t hits) {
                 LV(int, nextHit);
                 LANES({
@@ -357,10 +300,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 const bool any = w < 64;
                 uint64_t m = 0;
                 const unsigned long long tw1 = STAT_NOW(); (void)tw1;
-#if !defined(PLZ4_FAST_HOPS)
-#define PLZ4_FAST_HOPS 6
-#endif
-                for (int u = 0; u < PLZ4_FAST_HOPS; ++u) {
+                for (int u = 0; u < 6; ++u) {                           // (4 .. 8 unconditional hops measure the same on text)
                     const int n1 = RL(nextHit, w & 63);
                     m |= 1ull << (w & 63);
                     w = (w < 64) ? n1 : 64;
@@ -390,7 +330,6 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 E = probes | insBit0 | (hasPm & BALLOT(stA[I_] == LANE + 2));
                 STAT(P_CYC_E, STAT_NOW() - tw2);
             };
-#endif
             // ---- 4. first round, straight: walk -> commit -> verify, every step unconditional, ONE question at the end
             uint64_t committed = 0;
             bool giveUp = false;
@@ -410,10 +349,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 const uint64_t noRegs   = upd & BALLOT(rent[I_] != cur[I_].pk && (rent[I_] >> sh) < (uint32_t)base);
                 LV(bool, hitN); LV(int, fwdN); LV(Win20, Wn);
                 uint64_t diff = 0;
-#if !defined(PLZ4_VERIFY_ALWAYS)
-                if (upd)                     // (about half of the batches on text: worth the one conditional)
-#endif
-                {
+                if (upd) {                   // (about half of the batches on text: worth the one conditional)
                     LANES({
                         const bool u = (upd >> LANE) & 1;
                         ce[I_] = u ? rent[I_] : ce[I_];
@@ -447,15 +383,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                             committed = 0;
                         }
                         if (round == 4) { giveUp = true; break; }
-#if defined(PLZ4_TROUBLE_WALK_FAST)
-                        {
-                            const uint64_t hitsR = BALLOT(hit[I_]);
-                            walk_fast(hitsR);
-                            if (mm & hitsR & BALLOT(fwd[I_] == 16)) walk();    // a match longer than the window under the hop: measured
-                        }
-#else
                         walk();
-#endif
                         const uint64_t EL2 = E;
                         LANES({ if ((EL2 >> LANE) & 1) rent[I_] = lds_max_rtn(&T[cur[I_].h], cur[I_].ent); })
                         committed = EL2;

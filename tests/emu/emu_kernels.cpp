@@ -289,10 +289,8 @@ extern "C" int emu_compress_hc_lists(const uint8_t* src, int n, uint8_t* dst, in
     return hc_compress(E.padded, n, dst, cap, level, w);
 }
 
-// diagnostics of the level-1 parser's pipeline (lz4_seq_device.inl): [grid batches, cold starts, candidate windows reloaded from
-// memory, twin repairs, twin repairs that went to memory]; reset on read
+// diagnostics of the level-1 parser's pipeline (see plz4_emu_cnt in lz4_seq_device.inl); reset on read
 extern "C" void emu_parse_counters(unsigned long long* out8)
 {
     for (int i = 0; i < 8; ++i) { out8[i] = plz4::plz4_emu_cnt[i]; plz4::plz4_emu_cnt[i] = 0; }
 }
-extern "C" void emu_parse_deep(unsigned long long* out4) { for (int i = 0; i < 4; ++i) { out4[i] = plz4::plz4_emu_deep[i]; plz4::plz4_emu_deep[i] = 0; } }

@@ -297,6 +297,37 @@ def test_gpu_host_calls_in_many_chunks(orc, monkeypatch):
     e.close()
 
 
+def test_gpu_level1_in_groups(orc, monkeypatch):
+    """The staged level-1 call keeps 9 bytes of workspace per possible sequence of the blocks of one group; a call that does not
+    fit the memory set aside runs in groups of equal size.  A 40 MiB budget makes 4 MiB blocks go four to a group: records and raw
+    blocks of a 7-block call (one of them incompressible, the last one short) must not depend on it -- device-resident and host calls."""
+    import torch
+    from plz4_amd._native import Engine
+    monkeypatch.setenv("PLZ4HIP_L1_BUDGET_MIB", "40")
+    e = Engine(0)
+    bsz = 4 << 20
+    data = synth.make("M", 6 * bsz + 54321, bsz)
+    srcs = [data[o:o + bsz] for o in range(0, data.size, bsz)]
+    recs = e.encode_records(srcs, bsz, True)
+    for s_, r in zip(srcs, recs):
+        assert np.array_equal(r, orc.block_record(s_, bsz, True)), s_.size
+    res, outs = e.compress_batch(srcs, [orc.bound(s_.size) for s_ in srcs])
+    for s_, r, o in zip(srcs, res, outs):
+        n, want = orc.compress_fast(s_, orc.bound(s_.size))
+        assert int(r) == n and np.array_equal(o, want[:n])
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(data).to(dev)
+    stride = e.stage_stride(bsz)
+    d_stage = torch.zeros(len(srcs) * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(len(srcs), dtype=torch.int32, device=dev)
+    e.dev_encode_records(d_src.data_ptr(), data.size, bsz, True, d_stage.data_ptr(), d_len.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    lens = d_len.cpu().numpy(); stage = d_stage.cpu().numpy()
+    for i, r in enumerate(recs):
+        assert int(lens[i]) == r.size and np.array_equal(stage[i * stride:i * stride + r.size], r), i
+    e.close()
+
+
 def test_gpu_dev_compress_levels_and_trim(ref, orc):
     """plz4hip_dev_compress (raw blocks on the device) at level 1, a hash-chain level and level 12; plz4hip_ctx_trim gives the
     staging and HC workspaces back and the ctx keeps working."""
