@@ -36,6 +36,7 @@ enum : int {
 
 // per-block results of the parse / scan stages
 struct SeqInfo { int32_t nseq; int32_t lastAnchor; int32_t total; int32_t stored; };
+enum : int { kSeqEngineFailed = -2 };     // SeqInfo::nseq of a block whose parser had no input to trust (-1: not sized for; both: no records)
 
 // entries a block of n bytes can need: every sequence consumes at least MINMATCH input bytes.  The parser's array has one more
 // (a dump entry at index seq_capacity(n)).
@@ -648,6 +649,8 @@ DEV int seq_backext4(const uint8_t* __restrict__ src, int pos, int cnd, int maxB
 
 // bytes of the sequences [c*kSeqChunk, min(nseq, (c+1)*kSeqChunk)) of a block; their catch-up lengths go to bkOut[].
 // Four sequences per lane and trip: their loads are independent, so one memory round trip serves 256 sequences.
+// kBack = false: records that carry the final match (the HC parsers', lz4hc_lazy_device.inl): no catch-up, bkOut unused.
+template <bool kBack = true>
 DEV uint32_t seq_emit_sizes(const uint8_t* __restrict__ src, const uint64_t* __restrict__ seq, uint8_t* __restrict__ bkOut, int nseq, int c)
 {
     const int i0 = c * kSeqChunk, i1 = min_(nseq, i0 + kSeqChunk);
@@ -664,13 +667,13 @@ DEV uint32_t seq_emit_sizes(const uint8_t* __restrict__ src, const uint64_t* __r
             REC[I_] = seq[k_]; \
             AN[I_]  = seq_anchor(k_ ? seq[k_ - 1] : 0, k_ == 0); \
             const int pos_ = (int)seq_pos(REC[I_]), cnd_ = pos_ - (int)seq_off(REC[I_]); \
-            bool m_; \
-            BK[I_] = seq_backext4(src, pos_, cnd_, min_(pos_ - AN[I_], cnd_), &m_); \
+            bool m_ = false; \
+            BK[I_] = kBack ? seq_backext4(src, pos_, cnd_, min_(pos_ - AN[I_], cnd_), &m_) : 0; \
             MO[I_] = m_; \
         })
         SEQ_SZ_STEP(0, rec0, bk0, an0, mo0) SEQ_SZ_STEP(1, rec1, bk1, an1, mo1) SEQ_SZ_STEP(2, rec2, bk2, an2, mo2) SEQ_SZ_STEP(3, rec3, bk3, an3, mo3)
 #undef SEQ_SZ_STEP
-        if (BALLOT(mo0[I_] | mo1[I_] | mo2[I_] | mo3[I_])) {               // a catch-up beyond four bytes (rare): the loop
+        if (kBack && BALLOT(mo0[I_] | mo1[I_] | mo2[I_] | mo3[I_])) {               // a catch-up beyond four bytes (rare): the loop
 #define SEQ_SZ_MORE(REC, BK, AN, MO) \
             LANES({ if (MO[I_]) { const int pos_ = (int)seq_pos(REC[I_]), cnd_ = pos_ - (int)seq_off(REC[I_]); \
                                   BK[I_] = seq_backext_from(src, pos_, cnd_, min_(pos_ - AN[I_], cnd_), 4); } })
@@ -682,7 +685,7 @@ DEV uint32_t seq_emit_sizes(const uint8_t* __restrict__ src, const uint64_t* __r
             const int k_ = i + (U) * 64 + LANE; \
             if (k_ < i1) { \
                 acc[I_] += seq_layout(REC[I_], AN[I_], BK[I_]).size; \
-                bkOut[k_] = (uint8_t)min_(BK[I_], 255); \
+                if (kBack) bkOut[k_] = (uint8_t)min_(BK[I_], 255); \
             } \
         })
         SEQ_SZ_FIN(0, rec0, bk0, an0) SEQ_SZ_FIN(1, rec1, bk1, an1) SEQ_SZ_FIN(2, rec2, bk2, an2) SEQ_SZ_FIN(3, rec3, bk3, an3)
@@ -731,6 +734,7 @@ DEV void lane_copy(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, int l
 // Writes chunk c of a block at dst + chunkOff (token, literal length bytes, literals, offset, match length bytes per sequence:
 // lz4.c:1112-1226); the wave that writes the last chunk (or chunk 0 of a block without sequences) also writes the last
 // literals (lz4.c:1302-1329).  Long literal runs and long length-byte runs are left to the whole wave.
+template <bool kBack = true>
 DEV void seq_emit_write(const uint8_t* __restrict__ src, int n, const uint64_t* __restrict__ seq, const uint8_t* __restrict__ bkIn, int nseq, int lastAnchor, int c,
                         uint32_t chunkOff, uint8_t* __restrict__ dst)
 {
@@ -743,8 +747,8 @@ DEV void seq_emit_write(const uint8_t* __restrict__ src, int n, const uint64_t* 
             if (k < i1) {
                 const uint64_t rec = seq[k];
                 const int an = seq_anchor(k ? seq[k - 1] : 0, k == 0);
-                int bk = (int)bkIn[k];
-                if (bk == 255) { const int pos = (int)seq_pos(rec), cnd = pos - (int)seq_off(rec); bk = seq_backext_from(src, pos, cnd, min_(pos - an, cnd), 0); }
+                int bk = kBack ? (int)bkIn[k] : 0;
+                if (kBack && bk == 255) { const int pos = (int)seq_pos(rec), cnd = pos - (int)seq_off(rec); bk = seq_backext_from(src, pos, cnd, min_(pos - an, cnd), 0); }
                 so[I_] = seq_layout(rec, an, bk);
             }
             else { so[I_].anchor = 0; so[I_].lit = 0; so[I_].mlen = 0; so[I_].extL = 0; so[I_].extM = 0; so[I_].size = 0; so[I_].off = 0; }

@@ -73,13 +73,16 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
     for (int half = 0; half < 2; ++half) {
         LANES({ for (int i = LANE; i < kHcHashEntries / 2; i += 64) { lastT[i] = 0u; curT[i] = offsets[half * (kHcHashEntries / 2) + i]; } })
         LDS_FENCE();
-        for (int base = 0; base < nPad; base += 64) {
+        // the four source bytes of a step's 64 positions are requested four steps ahead: a step then costs its two LDS atomics
+        // and its stores, not a memory round trip (one wave per CU runs this: nothing else would hide it)
+        auto words = [&](LVREF(uint32_t, w), int b) { LANES({ const int p = b + LANE; w[I_] = p < nIns ? ld32u(src + p) : 0u; }) };
+        auto step = [&](const int base, LVREF(uint32_t, w)) {
             LV(uint32_t, h); LV(uint32_t, prev); LV(uint32_t, slot); LV(int, act);
             LANES({
                 const int p = base + LANE;
                 act[I_] = 0; h[I_] = 0; prev[I_] = 0; slot[I_] = 0;
                 if (p < nIns) {
-                    const uint32_t hv = hc12_hash(ld32u(src + p));
+                    const uint32_t hv = hc12_hash(w[I_]);
                     if ((int)(hv >> 14) == half) {
                         act[I_] = 1; h[I_] = hv & 16383u;
                         prev[I_] = lds_max_rtn(&lastT[h[I_]], (uint32_t)p + 1u);
@@ -87,7 +90,7 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
                     }
                 }
             })
-            LDS_FENCE();
+            LDS_ORDER();             // (the atomics' answers are waited for where they are used; no fence: it would wait for the loads ahead too)
             {   // in lane order, a lane whose predecessor is in this batch sits right behind it in the list
                 LV(uint32_t, ps);
                 LANES({ ps[I_] = SHFL(slot, (prev[I_] > (uint32_t)base) ? (int)(prev[I_] - 1u - (uint32_t)base) : LANE); })
@@ -118,6 +121,17 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
                     list[slot[I_]] = (uint32_t)p | (prev[I_] ? 0u : kHc12First);
                 } else if (p >= nIns && half == 0) chain[p] = 0;
             })
+        };
+        LV(uint32_t, w0); LV(uint32_t, w1); LV(uint32_t, w2); LV(uint32_t, w3);
+        words(w0, 0); words(w1, 64); words(w2, 128); words(w3, 192);
+        for (int base = 0; base < nPad; base += 256) {
+            LV(uint32_t, n0); LV(uint32_t, n1); LV(uint32_t, n2); LV(uint32_t, n3);
+            words(n0, base + 256); words(n1, base + 320); words(n2, base + 384); words(n3, base + 448);
+            step(base, w0);
+            if (base + 64 < nPad) step(base + 64, w1);
+            if (base + 128 < nPad) step(base + 128, w2);
+            if (base + 192 < nPad) step(base + 192, w3);
+            LANES({ w0[I_] = n0[I_]; w1[I_] = n1[I_]; w2[I_] = n2[I_]; w3[I_] = n3[I_]; })
         }
         LDS_FENCE();
     }

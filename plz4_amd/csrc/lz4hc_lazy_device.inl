@@ -1,0 +1,334 @@
+// lz4hc_lazy_device.inl -- HC levels 3..9 (the lazy hash-chain parser) for independent blocks, cut for a GPU: the waves that walk a
+// block only DECIDE -- searches with all 64 lanes, one 8-byte record per sequence; the block's bytes are written by the
+// data-parallel emit stage level 1 uses (lz4_seq_device.inl: one lane per sequence).
+//
+//   reference: /root/reference/internal/pkg/clz4/lz4hc.c
+//     LZ4HC_compress_hashChain :1121-1363 (nbSearches = 1 << (level-1), table :92-106; pattern analysis above 128 attempts)
+//     LZ4HC_InsertAndGetWiderMatch :884-1104, LZ4HC_encodeSequence :268-354, last literals :1330-1362
+//
+// What the reference's loop does, and where each part went:
+//   (1) Searches.  On an independent block every position below ip is in the chain when ip is searched (LZ4HC_Insert runs up to
+//       ip, :914), so the chain is a function of the data; it is built up front together with the per-hash lists
+//       (lz4hc12_device.inl: the candidates of a chain are consecutive list entries).  Levels 3..6 (4..32 attempts) search
+//       with hc_find_few: one candidate per lane, and for the FIRST search of a sequence (:1159 -- it runs at every position
+//       of a literal run until one finds something) 64 / attempts consecutive positions at once: three memory round trips
+//       serve 16 positions at level 3.  Levels 7..9 search with hc_find_wider_lists (63 candidates per round, pattern analysis).
+//       [Computing the first search of EVERY position ahead of the walk, one position per lane over the whole chip -- level
+//       12's scheme -- was built and measured here as well and lost at every level: the positions inside matches are searched
+//       for nothing.]
+//   (2) The sequence itself is not written here.  A record (position, length, offset) per sequence; lz4_seq_device.inl's emit
+//       kernels size, place and write them, 64 sequences per wave step, and hash the payload.  LZ4HC's output checks
+//       (:283-288, :323-327, :1340-1352) are conservative estimates of bytes that the rest of the block needs in any case (a token,
+//       the last five literals), so, as at level 1, "a check fails somewhere" == "the complete block is larger than the
+//       capacity": seq_emit_scan's verdict is LZ4_compress_HC's return value.  (Check 1 at a sequence: op + ll + ll/255 + 8 >
+//       oend, while the block needs at least op + 1 + ext(ll) + ll + 2 + ext(ml) + 6 with ext(ll) >= ll/255; check 2:
+//       op' + (ml-4)/255 + 6 > oend with ext(ml) >= (ml-4)/255; the last one, :1340, is exact.)
+//   (3) The decisions (:1177-1306: which of up to three overlapping matches goes first and how they are trimmed) are the
+//       reference's, one for one -- they are the format of the output -- but the loop is a three-state machine over
+//       (ip, m1, m2, m3) without output pointers, tables or inserts.
+//   (4) And the walk is cut into SEGMENTS that are walked at the same time.  Whenever the loop is back at its top (:1157, "no
+//       match in hand": the state kLzFirst below) everything it will do from there on is a function of ip and the data -- and
+//       already of q, the first position at or behind ip whose first search is not empty.  So a wave may start in that state at
+//       any position B_j: its records are the block's records from the first q on that the true walk -- the one from position
+//       0 -- also reaches in that state.  hc_lazy_segment walks [B_j, B_j+1) for every j at once and notes the first
+//       kLzStarts such q of each segment; hc_lazy_stitch then walks from where segment j-1 truly ended until it meets one
+//       of segment j's q (typically after a handful of sequences: a literal run re-synchronises the two walks), and the
+//       block's records are: segment 0, bridge 1, segment 1 from the meeting point on, bridge 2, ...  A bridge that meets
+//       nothing within the noted starts simply walks on to B_j+1 and replaces the segment.  The pieces are gathered into one
+//       array for the emit stage.  The serial work of one wave per block becomes S waves per block; the output is the one
+//       walk's, bit for bit.
+#pragma once
+#include "lz4hc12_device.inl"
+#include "lz4_seq_device.inl"
+
+namespace plz4 {
+
+enum : int { kLzFirst = 0, kLzSecond = 1, kLzThird = 2 };
+
+// Sequence records of one block, 64 at a time (one coalesced store)
+struct SeqSink {
+    uint64_t* seq; int n;
+    LV(uint64_t, buf);
+    DEVM void put(int pos, int ml, int off)
+    {
+        const uint64_t r = seq_pack((uint32_t)pos, (uint32_t)(ml - kMinMatch), (uint32_t)off);
+        const int slot = n & 63;
+        LANES({ if (LANE == slot) buf[I_] = r; })
+        ++n;
+        if ((n & 63) == 0) flush64(n - 64, 64);
+    }
+    DEVM void flush64(int base, int cnt) { LANES({ if (LANE < cnt) seq[base + LANE] = buf[I_]; }) }
+    DEVM void finish() { if (n & 63) flush64(n & ~63, n & 63); }
+};
+
+// LZ4HC_InsertAndGetWiderMatch without pattern analysis and chain swap for nb = 4..32 attempts, one candidate per lane.
+//   multi = false: the search at `pos` with look-back down to `low` and `longest` to beat (lanes 0..nb-1).
+//   multi = true : the first search (no look-back, nothing to beat) of the 64 / nb positions pos, pos+1, ... at once, lanes
+//                  [g*nb, (g+1)*nb) for position pos + g; the answer is the first position that finds a match.
+// A candidate's total is counted exactly; the reference's walk keeps the first candidate with the largest total above
+// `longest` (:934-939: a later one replaces it only when longer) -- its 2-byte filter (:921) never rejects a candidate that
+// would improve (the two bytes lie inside such a candidate's match because lookBack < longest at every call), so the answer
+// is the first maximum.  Candidates: the entries below the position in its chain's list, while the chain has not ended, the
+// distance is <= 65535 (:918; a saturated link, :1065, leads below that window as well) and attempts are left.
+struct LzFound { int pos, len, off, back; };          // pos < 0: nothing
+DEV LzFound hc_find_few(const HcState& s, const int pos, const int low, const int highLimit, const int longest, const int nb,
+                        const bool multi, const int mflimit)
+{
+    const uint8_t* const src = s.src;
+    const uint8_t* const iHigh = src + highLimit;
+    const int lookBack = pos - low;
+    LV(int, p); LV(int, ci); LV(int, q); LV(uint32_t, key); LV(int, bk);
+    LANES({
+        const int g = multi ? LANE / nb : 0;
+        ci[I_] = multi ? LANE % nb : LANE;
+        p[I_] = pos + g;
+        const bool act = multi ? p[I_] <= mflimit : LANE < nb;
+        uint32_t head = 0, rk = 0;
+        if (act) { head = s.w.pre[p[I_]]; rk = s.w.rank[p[I_]]; }
+        const int at = (int)rk - 1 - ci[I_];
+        uint32_t e = 0x80000000u;
+        if (act && head && at >= -8) e = s.w.list[at];
+        q[I_] = (int)(e & 0x7FFFFFFFu);
+        key[I_] = (act && head) ? (e >> 31) : 2u;             // for now: 1 = the chain's first position, 2 = no candidate here
+    })
+    const uint64_t firsts = BALLOT(key[I_] == 1u);
+    LANES({
+        const int g0 = multi ? LANE - ci[I_] : 0;               // my group's first lane
+        const uint64_t below = firsts & (((uint64_t)1 << LANE) - 1) & ~(((uint64_t)1 << g0) - 1);   // chain ended at a nearer candidate
+        const bool valid = key[I_] != 2u && !below && p[I_] - q[I_] <= 65535 && q[I_] < p[I_];
+        int total = 0; bk[I_] = 0;
+        if (valid) {
+            const uint8_t* const ipp = src + p[I_];
+            const uint8_t* const mp = src + q[I_];
+            if (ld32u(mp) == ld32u(ipp)) {                                                          // :930
+                const int back = lookBack ? hc_count_back(ipp, mp, src + low, src) : 0;              // :933 (<= 0)
+                total = kMinMatch + hc_count(ipp + kMinMatch, mp + kMinMatch, iHigh) - back;
+                bk[I_] = back;
+            }
+        }
+        key[I_] = ((uint32_t)total << 6) | (uint32_t)(63 - ci[I_]);                                  // largest total, nearest candidate first
+    })
+    for (int m = 1; m < nb; m <<= 1) {
+        LV(uint32_t, o);
+        LANES({ o[I_] = SHFL(key, LANE ^ m); })
+        LANES({ key[I_] = key[I_] > o[I_] ? key[I_] : o[I_]; })
+    }
+    LzFound f; f.pos = -1; f.len = longest; f.off = 0; f.back = 0;
+    const uint64_t hit = BALLOT(ci[I_] == 0 && (int)(key[I_] >> 6) > longest);
+    if (hit) {
+        const int l0 = multi ? ctz64(hit) : 0;
+        const uint32_t kk = RL(key, l0);
+        const int c = l0 + 63 - (int)(kk & 63u);
+        f.pos = RL(p, l0); f.len = (int)(kk >> 6); f.off = f.pos - RL(q, c); f.back = RL(bk, c);
+    }
+    return f;
+}
+
+// What a walk over part of a block leaves behind
+struct LzRun {
+    int cnt;        // records written
+    int endIp;      // where it stopped, in state kLzFirst (>= the stop position), unless ...
+    int finished;   // ... it reached the block's end: anchor = where the last literals start
+    int anchor;
+};
+enum : int { kLzStarts = 64 };      // meeting points noted per segment
+struct LzNoHook { DEVM bool operator()(int, int) const { return false; } };
+
+// Levels 3..9 of an independent block, from state kLzFirst at ipStart until that state is reached again at or behind ipStop (or
+// the block ends).  w.pre / w.rank / w.list = the block's chain and lists.  hook(q, records so far) is called whenever a first
+// match has been found at q, before anything is decided about it; returning true ends the walk there (endIp = q).  Records go
+// to seq[0..).
+template <class Hook>
+DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
+                      const int ipStart, const int ipStop, Hook& hook)
+{
+    const int  maxNb = 1 << (level - 1);
+    const bool pa = maxNb > 128;
+    HcState s; s.src = src; s.pfx = 0; s.w = w; s.nextToUpdate = 0; s.d.mode = kHcNone; s.d.len = 0; s.d.bytes = nullptr; s.d.hash = nullptr; s.d.chain = nullptr;
+    const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
+    const int kOptimalMl = 15 - 1 + kMinMatch;                                                   // OPTIMAL_ML, lz4hc.c:75
+    SeqSink out; out.seq = seq; out.n = 0;
+    LANES({ out.buf[I_] = 0; })
+    int ip = ipStart, anchor = ipStart;
+    LzRun run; run.cnt = 0; run.endIp = ipStart; run.finished = 1; run.anchor = ipStart;
+    if (n < kMinLength) return run;                                                              // :1155
+
+    const bool few = maxNb <= 32;                                // levels 3..6: one candidate per lane, first searches in groups
+    auto wider = [&](int pos, int low, int longest) {
+        if (few) { const LzFound f = hc_find_few(s, pos, low, matchlimit, longest, maxNb, false, mflimit); HcMatch m; m.len = f.len; m.off = f.off; m.back = f.back; return m; }
+        return hc_find_wider_lists(s, pos, low, matchlimit, longest, maxNb, pa, false);
+    };
+
+    int st = kLzFirst;
+    int start0 = 0, start2 = 0, start3 = 0;
+    HcMatch m0 = {0, 0, 0}, m1 = {0, 0, 0}, m2 = {0, 0, 0}, m3 = {0, 0, 0};
+    for (;;) {
+        if (st == kLzFirst) {
+            // the literal run: the first position at or behind ip whose first search found something (:1157-1162)
+            bool found = false;
+            if (ip >= ipStop && ip <= mflimit) { run.finished = 0; break; }
+            while (ip <= mflimit) {
+                if (few) {
+                    const LzFound f = hc_find_few(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, true, mflimit);
+                    if (f.pos < 0) { ip += 64 / maxNb; continue; }
+                    ip = f.pos; m1.len = f.len; m1.off = f.off; m1.back = 0;
+                } else {
+                    m1 = wider(ip, ip, kMinMatch - 1);
+                    if (m1.len < kMinMatch) { ip++; continue; }
+                }
+                found = true;
+                break;
+            }
+            if (!found) break;
+            if (hook(ip, out.n)) { run.finished = 0; break; }
+            start0 = ip; m0 = m1;
+            st = kLzSecond;
+        }
+        if (st == kLzSecond) {
+            // one match in hand: is there a longer one that starts inside it? (:1167-1196)
+            m2.len = 0; m2.off = 0; m2.back = 0;
+            if (ip + m1.len <= mflimit) {
+                start2 = ip + m1.len - 2;
+                m2 = wider(start2, ip, m1.len);
+                start2 += m2.back;
+            }
+            if (m2.len <= m1.len) {                                                              // no: m1 goes out
+                out.put(ip, m1.len, m1.off);
+                ip += m1.len; anchor = ip;
+                st = kLzFirst;
+                continue;
+            }
+            if (start0 < ip && start2 < ip + m0.len) { ip = start0; m1 = m0; }                   // :1186-1189
+            if (start2 - ip < 3) { ip = start2; m1 = m2; continue; }                             // m1 too short to keep: m2 takes its place
+            st = kLzThird;
+        }
+        // kLzThird -- two overlapping matches in hand: a third one? (:1198-1306)
+        if (start2 - ip < kOptimalMl) {                                                          // :1199-1210
+            int newMl = m1.len;
+            if (newMl > kOptimalMl) newMl = kOptimalMl;
+            if (ip + newMl > start2 + m2.len - kMinMatch) newMl = (start2 - ip) + m2.len - kMinMatch;
+            const int correction = newMl - (start2 - ip);
+            if (correction > 0) { start2 += correction; m2.len -= correction; }
+        }
+        m3.len = 0; m3.off = 0; m3.back = 0;
+        if (start2 + m2.len <= mflimit) {                                                        // :1212-1220
+            start3 = start2 + m2.len - 3;
+            m3 = wider(start3, start2, m2.len);
+            start3 += m3.back;
+        }
+        if (m3.len <= m2.len) {                                                                  // no: m1 (cut at m2's start) and m2 go out, :1222-1240
+            if (start2 < ip + m1.len) m1.len = start2 - ip;
+            out.put(ip, m1.len, m1.off);
+            out.put(start2, m2.len, m2.off);
+            ip = start2 + m2.len; anchor = ip;
+            st = kLzFirst;
+            continue;
+        }
+        if (start3 < ip + m1.len + 3) {                                                          // :1242-1270
+            if (start3 >= ip + m1.len) {                                                         // m3 leaves no room for m2: m1 goes out, m3 is the match in hand
+                if (start2 < ip + m1.len) {
+                    const int correction = ip + m1.len - start2;
+                    start2 += correction;
+                    m2.len -= correction;
+                    if (m2.len < kMinMatch) { start2 = start3; m2 = m3; }
+                }
+                out.put(ip, m1.len, m1.off);
+                anchor = ip + m1.len;
+                ip = start3; m1 = m3;
+                start0 = start2; m0 = m2;
+                st = kLzSecond;
+                continue;
+            }
+            start2 = start3; m2 = m3;                                                            // m3 swallows m2
+            continue;
+        }
+        if (start2 < ip + m1.len) {                                                              // three in a row: m1 goes out, :1277-1306
+            if (start2 - ip < kOptimalMl) {
+                if (m1.len > kOptimalMl) m1.len = kOptimalMl;
+                if (ip + m1.len > start2 + m2.len - kMinMatch) m1.len = (start2 - ip) + m2.len - kMinMatch;
+                const int correction = m1.len - (start2 - ip);
+                if (correction > 0) { start2 += correction; m2.len -= correction; }
+            } else m1.len = start2 - ip;
+        }
+        out.put(ip, m1.len, m1.off);
+        anchor = ip + m1.len;
+        ip = start2; m1 = m2;
+        start2 = start3; m2 = m3;
+    }
+    out.finish();
+    run.cnt = out.n; run.endIp = ip; run.anchor = anchor;
+    return run;
+}
+
+// ---- segments.  Layout of a block's workspace (entries of 8 bytes): rec[j * segCap ..): the records of segment j;
+// bridge[j * segCap ..): those of the walk that leads into it.  meta[j]: what the two walks left behind.
+struct LzSegMeta {
+    LzRun seg, bridge;
+    int nStarts;        // entries of starts[]: (q << 32) | records before it
+    int skip;           // stitched: the segment's records count from here on (== seg.cnt: none of them)
+    int pad0, pad1;
+};
+struct LzPiece { const uint64_t* src; int cnt; int dst; };
+DEV int lz_segments(int n, int maxSegs, int minSeg) { int s = n / (minSeg > 0 ? minSeg : 1); if (s > maxSegs) s = maxSegs; return s < 1 ? 1 : s; }
+DEV int lz_seg_len(int n, int segs) { return (n + segs - 1) / segs; }
+DEV int lz_seg_cap(int segLen) { return ((segLen / kMinMatch + 8) + 63) & ~63; }
+
+// pass 1, one wave per (block, segment)
+struct LzStartNote {
+    uint64_t* starts; int n;
+    DEVM bool operator()(int q, int recs)
+    {
+        if (n < kLzStarts) { const uint64_t v = ((uint64_t)(uint32_t)q << 32) | (uint32_t)recs; const int at = n; LANES({ if (LANE == 0) starts[at] = v; }) ++n; }
+        return false;
+    }
+};
+DEV void hc_lazy_segment(const uint8_t* __restrict__ src, int n, int level, HcWork w, int segs, int j,
+                         uint64_t* rec, LzSegMeta* meta, uint64_t* starts)
+{
+    const int segLen = lz_seg_len(n, segs), cap = lz_seg_cap(segLen);
+    LzStartNote note; note.starts = starts + (size_t)j * kLzStarts; note.n = 0;
+    const int b0 = j * segLen, b1 = j + 1 == segs ? n + 1 : (j + 1) * segLen;
+    const LzRun r = hc_lazy_run(src, n, level, w, rec + (size_t)j * cap, b0, b1, note);
+    const int ns = note.n;
+    LANES({ if (LANE == 0) { meta[j].seg = r; meta[j].nStarts = ns; meta[j].skip = 0; meta[j].bridge.cnt = 0; } })
+}
+
+// pass 2, one wave per block: from where the walk before segment j truly ended to a meeting point with segment j
+struct LzMeet {
+    const uint64_t* starts; int nStarts, at, skip, met;
+    DEVM bool operator()(int q, int)
+    {
+        while (at < nStarts && (int)(starts[at] >> 32) < q) ++at;
+        if (at < nStarts && (int)(starts[at] >> 32) == q) { met = 1; skip = (int)(uint32_t)starts[at]; return true; }
+        return false;
+    }
+};
+// pieces[0 .. 2*segs): what the block's records are, in order; returns their total, *lastAnchor as the one walk's
+DEV int hc_lazy_stitch(const uint8_t* __restrict__ src, int n, int level, HcWork w, int segs,
+                       uint64_t* rec, uint64_t* bridge, LzSegMeta* meta, const uint64_t* starts, LzPiece* pieces, int* lastAnchor)
+{
+    const int segLen = lz_seg_len(n, segs), cap = lz_seg_cap(segLen);
+    LzRun cur = meta[0].seg;                      // the true walk so far ends like this
+    int total = cur.cnt;
+    { const LzPiece p0 = { rec, cur.cnt, 0 }; const LzPiece none = { rec, 0, 0 }; LANES({ if (LANE == 0) { pieces[0] = none; pieces[1] = p0; } }) }
+    for (int j = 1; j < segs; ++j) {
+        LzPiece pb = { bridge + (size_t)j * cap, 0, total }, ps = { rec + (size_t)j * cap, 0, total };
+        const int b1 = j + 1 == segs ? n + 1 : (j + 1) * segLen;
+        if (!cur.finished && cur.endIp < b1) {
+            LzMeet meet; meet.starts = starts + (size_t)j * kLzStarts; meet.nStarts = meta[j].nStarts; meet.at = 0; meet.skip = 0; meet.met = 0;
+            const LzRun br = hc_lazy_run(src, n, level, w, bridge + (size_t)j * cap, cur.endIp, b1, meet);
+            pb.cnt = br.cnt;
+            total += br.cnt;
+            if (meet.met) {                          // from here on segment j's walk is the true one
+                ps.src += meet.skip; ps.cnt = meta[j].seg.cnt - meet.skip; ps.dst = total;
+                total += ps.cnt;
+                cur = meta[j].seg;
+            } else cur = br;                         // (ran into the next segment, or to the block's end)
+        }
+        LANES({ if (LANE == 0) { pieces[2 * j] = pb; pieces[2 * j + 1] = ps; } })
+    }
+    *lastAnchor = cur.anchor;
+    return total;
+}
+
+}  // namespace plz4

@@ -23,6 +23,7 @@ __device__ unsigned long long plz4_stats[24];
 #include "lz4_seq_device.inl"
 #include "lz4hc_device.inl"
 #include "lz4hc12_device.inl"
+#include "lz4hc_lazy_device.inl"
 
 namespace {
 
@@ -69,6 +70,10 @@ struct CodecArgs {
     uint32_t*       l1ChunkBytes; uint32_t* l1ChunkOff; int l1MaxChunks;   // per block: bytes of / before every chunk of 1024 sequences
     uint8_t*        l1Bk;                                    // per sequence: its catch-up length (l1SeqStride bytes per block)
     int             l1MaxLen;                                // what the workspace was sized for
+    // levels 3..9 (lz4hc_lazy_device.inl): a block is walked in up to lzSegs segments of at least lzMinSeg bytes at once
+    int             lzSegs, lzMinSeg;
+    uint64_t*       lzRec;      uint64_t* lzBridge;  int64_t lzRecStride;     // records of the segments / of the walks into them, entries per block
+    LzSegMeta*      lzMeta;     uint64_t* lzStarts;  LzPiece* lzPieces;       // per block: lzSegs, lzSegs * kLzStarts, 2 * lzSegs entries
 };
 
 __device__ __forceinline__ int next_block(uint32_t* q)
@@ -151,8 +156,9 @@ template <int W> __global__ __launch_bounds__(64 * W) void k_l1_parse(CodecArgs 
     }
 }
 
-// grid (waves per block / 4, blocks of the group): bytes of every chunk of 1024 sequences
-__global__ __launch_bounds__(256) void k_l1_sizes(CodecArgs a)
+// grid (waves per block / 4, blocks of the group): bytes of every chunk of 1024 sequences.  kBack: the level-1 parser's records
+// (their catch-up is measured here); false: the HC parsers' records, which carry the final match.
+template <bool kBack> __global__ __launch_bounds__(256) void k_l1_sizes(CodecArgs a)
 {
     const int i = blockIdx.y, wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6), nW = gridDim.x * 4;
     const int nseq = a.l1Info[i].nseq;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void k_l1_sizes(CodecArgs a)
     const uint64_t* seq = a.l1Seq + (int64_t)i * a.l1SeqStride;
     const int nChunks = (nseq + kSeqChunk - 1) / kSeqChunk;
     for (int c = wave; c < nChunks; c += nW) {
-        const uint32_t v = seq_emit_sizes(s, seq, a.l1Bk + (int64_t)i * a.l1SeqStride, nseq, c);
+        const uint32_t v = seq_emit_sizes<kBack>(s, seq, kBack ? a.l1Bk + (int64_t)i * a.l1SeqStride : nullptr, nseq, c);
         if ((threadIdx.x & 63u) == 0) a.l1ChunkBytes[(int64_t)i * a.l1MaxChunks + c] = v;
     }
 }
@@ -179,12 +185,14 @@ __global__ __launch_bounds__(256) void k_l1_scan(CodecArgs a)
     SeqInfo inf = a.l1Info[i];
     const int cap = a.rawMode ? (a.dstCap ? a.dstCap[gi] : a.dstCapAll) : a.bsz;     // records: capacity == bsz (blk/blk.go:73)
     int total = 0;
+    const bool broken = inf.nseq == kSeqEngineFailed;                                 // (an HC search phase that gave up: no result)
     if (inf.nseq >= 0)
         total = seq_emit_scan(a.l1ChunkBytes + (int64_t)i * a.l1MaxChunks, a.l1ChunkOff + (int64_t)i * a.l1MaxChunks, inf.nseq, inf.lastAnchor, n, cap);
     if ((threadIdx.x & 63u) == 0) {
         inf.total = total; inf.stored = (total == 0);
         a.l1Info[i] = inf;
-        if (a.rawMode) a.result[gi] = total;
+        if (broken) a.result[gi] = PLZ4HIP_E_DEVICE;
+        else if (a.rawMode) a.result[gi] = total;
         else {
             const int c = total ? total : n;                                          // ErrCompress -> stored raw (blk.go:78-92)
             st32u(a.dst + (int64_t)gi * a.dstStride, total ? ((uint32_t)c & 0x7FFFFFFFu) : (0x80000000u | ((uint32_t)n & 0x7FFFFFFFu)));
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void k_l1_scan(CodecArgs a)
 }
 
 // grid as k_l1_sizes: every chunk written at its place; a record whose encoder returned 0 gets the plaintext instead
-__global__ __launch_bounds__(256) void k_l1_write(CodecArgs a)
+template <bool kBack> __global__ __launch_bounds__(256) void k_l1_write(CodecArgs a)
 {
     const int i = blockIdx.y, wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6), nW = gridDim.x * 4;
     const SeqInfo inf = a.l1Info[i];
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(256) void k_l1_write(CodecArgs a)
         const uint64_t* seq = a.l1Seq + (int64_t)i * a.l1SeqStride;
         const int nChunks = (inf.nseq + kSeqChunk - 1) / kSeqChunk;
         for (int c = wave; c < (nChunks ? nChunks : 1); c += nW)
-            seq_emit_write(s, n, seq, a.l1Bk + (int64_t)i * a.l1SeqStride, inf.nseq, inf.lastAnchor, c, nChunks ? a.l1ChunkOff[(int64_t)i * a.l1MaxChunks + c] : 0u, out);
+            seq_emit_write<kBack>(s, n, seq, kBack ? a.l1Bk + (int64_t)i * a.l1SeqStride : nullptr, inf.nseq, inf.lastAnchor, c, nChunks ? a.l1ChunkOff[(int64_t)i * a.l1MaxChunks + c] : 0u, out);
     } else if (!a.rawMode && n > 0) {
         const int slice = (((n + nW - 1) / nW) + 15) & ~15;
         const int off = wave * slice;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void k_l1_finish(CodecArgs a)
     const int c = inf.total ? inf.total : block_len(a, gi);
     uint8_t* rec = a.dst + (int64_t)gi * a.dstStride;
     const uint32_t x = wave_xxh32_staged(rec + 4, c, stagebuf[threadIdx.x >> 6]);
-    if ((threadIdx.x & 63u) == 0) { st32u(rec + 4 + c, x); a.result[gi] = c + 8; }
+    if ((threadIdx.x & 63u) == 0) { st32u(rec + 4 + c, x); a.result[gi] = inf.nseq == kSeqEngineFailed ? PLZ4HIP_E_DEVICE : c + 8; }
 }
 
 // One level-1 block under a dictionary context and/or after another linked block.  Every input block of such a call has
@@ -734,6 +742,64 @@ __global__ __launch_bounds__(64) void k_hc12_parse(CodecArgs a)
     }
 }
 
+// Levels 3..9 on independent blocks (lz4hc_lazy_device.inl), the chain and the lists being there.  k_hc_lazy: one wave per
+// (block, segment) walks its segment and writes records; k_hc_stitch: one wave per block joins the segments' walks into the
+// one walk from position 0; k_hc_gather lays the pieces out as one array; the emit kernels of level 1 (k_l1_sizes<false> ..
+// k_l1_finish) make the block from it.
+__device__ __forceinline__ HcWork lz_work(const CodecArgs& a, int g)
+{
+    HcWork w; w.hash = nullptr; w.chain = nullptr; w.opt = nullptr; w.pre = nullptr; w.rank = nullptr; w.list = nullptr;
+    return hc_with_pre(w, a, g);
+}
+__global__ __launch_bounds__(64) void k_hc_lazy(CodecArgs a)
+{
+    const int items = a.nBlocks * a.lzSegs;
+    const bool broken = plz4_readfirstlane(*(volatile int32_t*)a.h12Err) != 0;
+    for (int it = next_block(a.queue); it < items; it = next_block(a.queue)) {
+        const int g = it / a.lzSegs, j = it - g * a.lzSegs;                  // (a block's segments are taken one after the other)
+        const int i = a.blk0 + g;
+        const int n = block_len(a, i);
+        if (broken || n < 0 || n > a.l1MaxLen) continue;
+        const int segs = lz_segments(n, a.lzSegs, a.lzMinSeg);
+        if (j >= segs) continue;
+        hc_lazy_segment(a.src + (int64_t)i * a.srcStride, n, a.level, lz_work(a, g), segs, j,
+                        a.lzRec + (int64_t)g * a.lzRecStride, a.lzMeta + (int64_t)g * a.lzSegs, a.lzStarts + (int64_t)g * a.lzSegs * kLzStarts);
+    }
+}
+__global__ __launch_bounds__(64) void k_hc_stitch(CodecArgs a)
+{
+    const bool broken = plz4_readfirstlane(*(volatile int32_t*)a.h12Err) != 0;
+    for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
+        const int i = a.blk0 + g;
+        const int n = block_len(a, i);
+        LzPiece* const pieces = a.lzPieces + (int64_t)g * 2 * a.lzSegs;
+        int lastAnchor = 0, nseq = -1, segs = 0;                             // -1: a block the workspace was not sized for
+        if (broken) nseq = kSeqEngineFailed;                                 // the search phase gave up: its F is not to be trusted
+        else if (n >= 0 && n <= a.l1MaxLen) {
+            segs = lz_segments(n, a.lzSegs, a.lzMinSeg);
+            nseq = hc_lazy_stitch(a.src + (int64_t)i * a.srcStride, n, a.level, lz_work(a, g), segs,
+                                  a.lzRec + (int64_t)g * a.lzRecStride, a.lzBridge + (int64_t)g * a.lzRecStride,
+                                  a.lzMeta + (int64_t)g * a.lzSegs, a.lzStarts + (int64_t)g * a.lzSegs * kLzStarts, pieces, &lastAnchor);
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            for (int k = 2 * segs; k < 2 * a.lzSegs; ++k) pieces[k].cnt = 0;
+            SeqInfo inf; inf.nseq = nseq; inf.lastAnchor = lastAnchor; inf.total = 0; inf.stored = 0; a.l1Info[g] = inf;
+        }
+    }
+}
+// grid (workgroups per block, blocks of the group)
+__global__ __launch_bounds__(256) void k_hc_gather(CodecArgs a)
+{
+    const int g = blockIdx.y;
+    const LzPiece* const pieces = a.lzPieces + (int64_t)g * 2 * a.lzSegs;
+    uint64_t* const seq = a.l1Seq + (int64_t)g * a.l1SeqStride;
+    const int t = blockIdx.x * 256 + (int)threadIdx.x, nT = gridDim.x * 256;
+    for (int k = 0; k < 2 * a.lzSegs; ++k) {
+        const LzPiece pc = pieces[k];
+        for (int e = t; e < pc.cnt; e += nT) seq[pc.dst + e] = pc.src[e];
+    }
+}
+
 // clz4.NewDictCtxHC (clz4.go:122-147): workgroup 0 builds the level-2 (lz4mid) tables of a dictionary, workgroup 1 the
 // hash-chain tables every other level shares.  tabs = 2 x kHcWorkBytes.
 __global__ __launch_bounds__(64) void k_hc_dict_prime(const uint8_t* dict, int len, uint8_t* tabs)
@@ -892,7 +958,7 @@ struct plz4hip_ctx {
     HostSlot     slot[kSlots];
     uint8_t*     d_hc = nullptr;   int hcWaves = 0;     // HC workspace, one slot per resident HC wave (allocated on first use)
     // level 12 in three phases: chain + search results of one group of blocks, the parser's table overflow, an error flag
-    uint8_t*     d_h12 = nullptr;  size_t h12Bytes = 0;  int h12ParseWaves = 0;  size_t h12ErrOff = 0;
+    uint8_t*     d_h12 = nullptr;  size_t h12Bytes = 0;  int h12ParseWaves = 0;  int hcLazyWaves = 0;  size_t h12ErrOff = 0;
     // Both HC workspaces belong to one job at a time: the stream of the last HC job and an event recorded behind it; an HC
     // job on another stream waits for that event on the device (no host block).
     hipEvent_t   hcDone = nullptr; hipStream_t hcStream = nullptr; bool hcPending = false;
@@ -1052,12 +1118,20 @@ size_t hc_default_budget(size_t freeBytes) { const size_t q = freeBytes / 4, cap
 // Level 12 on independent blocks without dictionary runs in three phases per group of blocks (lz4hc12_device.inl):
 // chain -> search results -> parser.  Per block the group workspace holds the chain (2 B per position) and F (8 B per
 // position); the group size follows from the memory set aside (PLZ4HIP_HC12_GROUP overrides, for tests).
-struct H12Plan { int64_t chainStride, fStride; size_t perBlock; int group; size_t offRank, offList, offOffsets, offF, offWs, offErr, total; };
-int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
+struct H12Plan { int64_t chainStride, fStride; size_t perBlock; int group; size_t offRank, offList, offOffsets, offF, offWs, offErr, total;
+                 int maxChunks; size_t offInfo, offChunkB, offChunkO;       // (the emit stage's small arrays: levels 3..9)
+                 int64_t recStride; size_t offRec, offBridge, offMeta, offStarts, offPieces; };   // (segments: levels 3..9)
+constexpr int kLzMaxSegs = 16;
+int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl, bool lazy)
 {
     pl->chainStride = (int64_t)round_up((size_t)maxLen + 1, 1024);
     pl->fStride = (int64_t)round_up((size_t)(maxLen > 11 ? maxLen - 11 : 1), 64);
-    pl->perBlock = (size_t)pl->chainStride * 2 + (size_t)pl->chainStride * 4 + ((size_t)pl->chainStride + 8) * 4 + (size_t)kHcHashEntries * 4 + (size_t)pl->fStride * 8;
+    if (lazy) pl->fStride = (int64_t)round_up((size_t)maxLen / 4 + 64, 64);          // no search results there: only the block's final records
+    pl->maxChunks = (int)((round_up((size_t)maxLen / 4 + 3, 64) + kSeqChunk - 1) / kSeqChunk);
+    pl->perBlock = (size_t)pl->chainStride * 2 + (size_t)pl->chainStride * 4 + ((size_t)pl->chainStride + 8) * 4 + (size_t)kHcHashEntries * 4 + (size_t)pl->fStride * 8
+                 + sizeof(SeqInfo) + (size_t)pl->maxChunks * 8;
+    pl->recStride = (int64_t)round_up((size_t)maxLen / 4 + (size_t)kLzMaxSegs * 80, 64);
+    if (lazy) pl->perBlock += (size_t)pl->recStride * 16 + (size_t)kLzMaxSegs * (sizeof(LzSegMeta) + kLzStarts * 8 + 2 * sizeof(LzPiece));
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");
     // hc_default_budget of what is free (and whatever the ctx holds already) unless PLZ4HIP_HC_BUDGET_GIB says more: the parser runs
@@ -1087,7 +1161,18 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
         pl->offF = pl->offOffsets + round_up((size_t)pl->group * (size_t)kHcHashEntries * 4, 256);
         pl->offWs = pl->offF + round_up((size_t)pl->group * (size_t)pl->fStride * 8, 256);
         pl->offErr = 0;
-        pl->total = pl->offWs + round_up((size_t)c->h12ParseWaves * kHc12WsGlobalBytes, 256);
+        pl->offInfo = pl->offWs + round_up((size_t)c->h12ParseWaves * kHc12WsGlobalBytes, 256);
+        pl->offChunkB = pl->offInfo + round_up((size_t)pl->group * sizeof(SeqInfo), 256);
+        pl->offChunkO = pl->offChunkB + round_up((size_t)pl->group * (size_t)pl->maxChunks * 4, 256);
+        pl->offRec = pl->offChunkO + round_up((size_t)pl->group * (size_t)pl->maxChunks * 4, 256);
+        pl->total = pl->offRec;
+        if (lazy) {
+            pl->offBridge = pl->offRec + round_up((size_t)pl->group * (size_t)pl->recStride * 8, 256);
+            pl->offMeta = pl->offBridge + round_up((size_t)pl->group * (size_t)pl->recStride * 8, 256);
+            pl->offStarts = pl->offMeta + round_up((size_t)pl->group * kLzMaxSegs * sizeof(LzSegMeta), 256);
+            pl->offPieces = pl->offStarts + round_up((size_t)pl->group * kLzMaxSegs * kLzStarts * 8, 256);
+            pl->total = pl->offPieces + round_up((size_t)pl->group * kLzMaxSegs * 2 * sizeof(LzPiece), 256);
+        }
         if (getenv("PLZ4HIP_VERBOSE"))
             fprintf(stderr, "plz4hip: level 12, %d blocks: free %zu MiB, held %zu MiB, groups of %d (%zu MiB)\n", nBlocks, freeB >> 20, c->h12Bytes >> 20, pl->group, pl->total >> 20);
         if (pl->total <= c->h12Bytes) break;
@@ -1109,21 +1194,38 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl)
 
 // (blocks of 8 MiB and more -- raw block API only -- keep the one-thread-per-block kernel: the writer packs positions into 23 bits)
 bool use_h12(const CodecArgs& a, int maxLen) { return a.level >= 12 && !a.hcEx && maxLen < (1 << 23) && getenv("PLZ4HIP_HC12_OFF") == nullptr; }
+// levels 3..9, independent blocks up to 4 MiB: first searches ahead, deciding parser, record emit (lz4hc_lazy_device.inl)
+bool use_lazy(const CodecArgs& a, int maxLen) { return a.level >= 3 && a.level <= 9 && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_LAZY_OFF") == nullptr; }
 
 // Enqueue one HC call of nb blocks (a: everything but queue / workspace filled in) on s.  rawMode: LZ4 blocks, else records.
 int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode)
 {
     if (int rc = hc_enter(c, s)) return rc;
     hipError_t e;
-    if (use_h12(a, maxLen)) {
+    const bool lazy = use_lazy(a, maxLen);
+    if (lazy || use_h12(a, maxLen)) {
         H12Plan pl;
-        if (int rc = plan_h12(c, nb, maxLen, &pl)) return rc;
+        if (int rc = plan_h12(c, nb, maxLen, &pl, lazy)) return rc;
         a.h12Chain = (uint16_t*)(c->d_h12 + 256); a.h12ChainStride = pl.chainStride;
         a.h12Rank = (uint32_t*)(c->d_h12 + pl.offRank); a.h12List = (uint32_t*)(c->d_h12 + pl.offList);
         a.h12Offsets = (uint32_t*)(c->d_h12 + pl.offOffsets);
         a.h12F = (Hc12F*)(c->d_h12 + pl.offF); a.h12FStride = pl.fStride;
         a.h12Ws = c->d_h12 + pl.offWs; a.h12Err = (int32_t*)(c->d_h12 + pl.offErr); c->h12ErrOff = pl.offErr;
         a.rawMode = rawMode;
+        if (lazy) {
+            if (!c->hcLazyWaves) {
+                int per = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc_lazy, 64, 0) != hipSuccess || per < 1) per = 8;
+                c->hcLazyWaves = c->cus * per;
+            }
+            a.l1MaxLen = maxLen; a.l1Seq = (uint64_t*)a.h12F; a.l1SeqStride = pl.fStride; a.l1MaxChunks = pl.maxChunks; a.l1Bk = nullptr;
+            a.l1Info = (SeqInfo*)(c->d_h12 + pl.offInfo);
+            a.l1ChunkBytes = (uint32_t*)(c->d_h12 + pl.offChunkB); a.l1ChunkOff = (uint32_t*)(c->d_h12 + pl.offChunkO);
+            a.lzRec = (uint64_t*)(c->d_h12 + pl.offRec); a.lzBridge = (uint64_t*)(c->d_h12 + pl.offBridge); a.lzRecStride = pl.recStride;
+            a.lzMeta = (LzSegMeta*)(c->d_h12 + pl.offMeta); a.lzStarts = (uint64_t*)(c->d_h12 + pl.offStarts); a.lzPieces = (LzPiece*)(c->d_h12 + pl.offPieces);
+            a.lzMinSeg = 65536;
+            if (const char* v = getenv("PLZ4HIP_HC_MIN_SEG")) { const int m = atoi(v); if (m >= 64) a.lzMinSeg = m; }     // tests: many segments in small blocks
+        }
         a.h12Gather = 12; a.h12Idle = 16;
         if (const char* v = getenv("PLZ4HIP_HC12_GATHER")) a.h12Gather = atoi(v);
         if (const char* v = getenv("PLZ4HIP_HC12_IDLE")) a.h12Idle = atoi(v);
@@ -1138,9 +1240,27 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);
             hipLaunchKernelGGL(k_hc12_chain, dim3(grid_for(ng, c->cus)), dim3(64), 0, s, a);
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-            hipLaunchKernelGGL(k_hc12_search, dim3(grid_for(ng, c->cus)), dim3(1024), 0, s, a);
+            if (!lazy) hipLaunchKernelGGL(k_hc12_search, dim3(grid_for(ng, c->cus)), dim3(1024), 0, s, a);
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-            hipLaunchKernelGGL(k_hc12_parse, dim3(grid_for(ng, c->h12ParseWaves)), dim3(64), 0, s, a);
+            if (!lazy) hipLaunchKernelGGL(k_hc12_parse, dim3(grid_for(ng, c->h12ParseWaves)), dim3(64), 0, s, a);
+            else {
+                // segments per block: measured at 2048 blocks of 4 MiB, level 3: 4 -> 5525, 8 -> 6197, 16 -> 6403 MiB/s -- more
+                // walks than the chip holds waves still pay (they even out the segments' lengths)
+                a.lzSegs = kLzMaxSegs;
+                if (const char* v = getenv("PLZ4HIP_HC_SEGS")) a.lzSegs = atoi(v);
+                a.lzSegs = a.lzSegs < 1 ? 1 : (a.lzSegs > kLzMaxSegs ? kLzMaxSegs : a.lzSegs);
+                hipLaunchKernelGGL(k_hc_lazy, dim3(grid_for(ng * a.lzSegs, c->hcLazyWaves)), dim3(64), 0, s, a);
+                a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+                hipLaunchKernelGGL(k_hc_stitch, dim3(grid_for(ng, c->hcLazyWaves)), dim3(64), 0, s, a);
+                hipLaunchKernelGGL(k_hc_gather, dim3(ng >= 1024 ? 4 : 16, ng), dim3(256), 0, s, a);
+                int wg = (16384 / ng) / 4;                                  // emit: waves per block so that a small call still spreads over the chip
+                if (wg > (pl.maxChunks + 3) / 4) wg = (pl.maxChunks + 3) / 4;
+                if (wg < 1) wg = 1;
+                hipLaunchKernelGGL(k_l1_sizes<false>, dim3(wg, ng), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(k_l1_scan, dim3((ng + 3) / 4), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(k_l1_write<false>, dim3(wg, ng), dim3(256), 0, s, a);
+                if (!rawMode && a.blockChecksum) hipLaunchKernelGGL(k_l1_finish, dim3((ng + 3) / 4), dim3(256), 0, s, a);
+            }
             HIPCHK(c, hipGetLastError());
         }
     } else {
@@ -1305,9 +1425,9 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         int wg = (16384 / ng) / 4;
         if (wg > (maxChunks + 3) / 4) wg = (maxChunks + 3) / 4;
         if (wg < 1) wg = 1;
-        hipLaunchKernelGGL(k_l1_sizes, dim3(wg, ng), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_l1_sizes<true>, dim3(wg, ng), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_l1_scan, dim3((ng + 3) / 4), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_l1_write, dim3(wg, ng), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(k_l1_write<true>, dim3(wg, ng), dim3(256), 0, s, a);
         if (!rawMode && a.blockChecksum) hipLaunchKernelGGL(k_l1_finish, dim3((ng + 3) / 4), dim3(256), 0, s, a);
         HIPCHK(c, hipGetLastError());
     }

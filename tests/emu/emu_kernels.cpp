@@ -289,6 +289,48 @@ extern "C" int emu_compress_hc_lists(const uint8_t* src, int n, uint8_t* dst, in
     return hc_compress(E.padded, n, dst, cap, level, w);
 }
 
+// ---- HC levels 3..9 as the kernels run them for independent blocks (lz4hc_lazy_device.inl): lists, the first search of every
+// position (Hc12Walk with the level's parameters; ncEvery > 0: every ncEvery-th one left to the parser), the deciding parser
+// that writes records over F, the emit stage without catch-up.
+#include "../../plz4_amd/csrc/lz4hc_lazy_device.inl"
+namespace {
+int emu_emit_records(const uint8_t* src, int n, const uint64_t* seq, int nseq, int lastAnchor, uint8_t* dst, int cap)
+{
+    using namespace plz4;
+    const int nChunks = (nseq + kSeqChunk - 1) / kSeqChunk;
+    uint32_t* cb = (uint32_t*)malloc((size_t)(nChunks + 1) * 4);
+    uint32_t* co = (uint32_t*)malloc((size_t)(nChunks + 1) * 4);
+    co[0] = 0;
+    for (int c = 0; c < nChunks; ++c) cb[c] = seq_emit_sizes<false>(src, seq, nullptr, nseq, c);
+    const int total = seq_emit_scan(cb, co, nseq, lastAnchor, n, cap);
+    if (total > 0) for (int c = 0; c < (nChunks ? nChunks : 1); ++c) seq_emit_write<false>(src, n, seq, nullptr, nseq, lastAnchor, c, co[c], dst);
+    free(cb); free(co);
+    return total;
+}
+}
+extern "C" int emu_compress_hc_lazy(const uint8_t* src, int n, uint8_t* dst, int cap, int level, int maxSegs, int minSeg)
+{
+    using namespace plz4;
+    if (n < 0 || n > kSeqMaxBlock) return -1;
+    H12Emu E(src, n);
+    HcWork w = emu_hc_work(nullptr);
+    w.pre = E.chain; w.rank = E.rank; w.list = E.listBase + 8;
+    // pass 1: every segment; pass 2: the bridges; pass 3: the pieces gathered into one array
+    const int segs = lz_segments(n, maxSegs, minSeg), segCap = lz_seg_cap(lz_seg_len(n, segs));
+    uint64_t* rec = (uint64_t*)malloc((size_t)segs * segCap * 8), *bridge = (uint64_t*)malloc((size_t)segs * segCap * 8);
+    uint64_t* starts = (uint64_t*)malloc((size_t)segs * kLzStarts * 8);
+    LzSegMeta* meta = (LzSegMeta*)malloc(sizeof(LzSegMeta) * (size_t)segs);
+    LzPiece* pieces = (LzPiece*)malloc(sizeof(LzPiece) * 2 * (size_t)segs);
+    for (int j = segs - 1; j >= 0; --j) hc_lazy_segment(E.padded, n, level, w, segs, j, rec, meta, starts);
+    int lastAnchor = 0;
+    const int nseq = hc_lazy_stitch(E.padded, n, level, w, segs, rec, bridge, meta, starts, pieces, &lastAnchor);
+    uint64_t* seq = (uint64_t*)malloc(((size_t)n / 4 + 64) * 8);
+    for (int k = 0; k < 2 * segs; ++k) for (int i = 0; i < pieces[k].cnt; ++i) seq[pieces[k].dst + i] = pieces[k].src[i];
+    const int r = emu_emit_records(E.padded, n, seq, nseq, lastAnchor, dst, cap);
+    free(seq); free(rec); free(bridge); free(starts); free(meta); free(pieces);
+    return r;
+}
+
 // diagnostics of the level-1 parser's pipeline (see plz4_emu_cnt in lz4_seq_device.inl); reset on read
 extern "C" void emu_parse_counters(unsigned long long* out8)
 {

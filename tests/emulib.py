@@ -12,7 +12,7 @@ from orclib import ROOT, _ptr, u8p
 
 EMU_SRC = os.path.join(ROOT, "tests", "emu", "emu_kernels.cpp")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "_build", "libemu.so")
-DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "lz4_seq_device.inl", "lz4hc_device.inl", "lz4hc12_device.inl", "wave.h")]
+DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "lz4_seq_device.inl", "lz4hc_device.inl", "lz4hc12_device.inl", "lz4hc_lazy_device.inl", "wave.h")]
 
 
 def build_emu():
@@ -113,6 +113,14 @@ class Emu:
         self.L.emu_hc12_search_check.restype = C.c_int
         self.L.emu_hc12_search_check.argtypes = [u8p, C.c_int, C.c_void_p]
         return int(self.L.emu_hc12_search_check(_ptr(src) if src.size else C.cast(None, u8p), src.size, None))
+
+    def compress_hc_lazy(self, src, cap, level, max_segs=1, min_seg=65536):
+        """Levels 3..9 as the kernels run them: segments walked independently, stitched, record emit (lz4hc_lazy_device.inl)."""
+        self.L.emu_compress_hc_lazy.restype = C.c_int
+        self.L.emu_compress_hc_lazy.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        dst = np.zeros(max(cap, 1) + 64, dtype=np.uint8)
+        r = int(self.L.emu_compress_hc_lazy(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, level, max_segs, min_seg))
+        return r, dst[:max(r, 0)]
 
     def compress_hc_pre(self, src, cap, level):
         """HC levels 3..11 with the chain built up front (what the kernels run for independent blocks without dictionary)."""

@@ -82,6 +82,29 @@ def test_gpu_hc_vs_reference(ref, orc):
 
 
 @pytest.mark.gpu
+def test_gpu_hc_lazy_levels_in_segments(ref, orc, monkeypatch):
+    """Levels 3..9 walk a block in segments at once and stitch the walks (lz4hc_lazy_device.inl).  Small segments in small
+    blocks: many stitches per block, walks that meet late or never (the pattern blocks); and the old one-wave path switched
+    on instead (PLZ4HIP_HC_LAZY_OFF) still gives the same bytes."""
+    from plz4_amd._native import Engine
+    cases = [c for c in _cases() if c[1].size <= 150000] + [c for c in _lazy_cases() if c[0].startswith("P")]
+    srcs = [s for _, s in cases]
+    want = {lvl: [ref.compress_hc(s, orc.bound(s.size), lvl) for s in srcs] for lvl in (3, 4, 6, 9)}
+    for env in ({"PLZ4HIP_HC_MIN_SEG": "2048", "PLZ4HIP_HC_SEGS": "16"}, {"PLZ4HIP_HC_MIN_SEG": "20000", "PLZ4HIP_HC_SEGS": "3"},
+                {"PLZ4HIP_HC_LAZY_OFF": "1"}):
+        for k in ("PLZ4HIP_HC_MIN_SEG", "PLZ4HIP_HC_SEGS", "PLZ4HIP_HC_LAZY_OFF"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = Engine(0)
+        for lvl in (3, 4, 6, 9):
+            res, outs = eng.compress_batch(srcs, [orc.bound(s.size) for s in srcs], level=lvl)
+            for (name, s), r, o, (a, da) in zip(cases, res, outs, want[lvl]):
+                assert int(r) == a and np.array_equal(o, da), (env, name, s.size, lvl)
+        eng.close()
+
+
+@pytest.mark.gpu
 def test_gpu_hc_golden_and_frame(orc):
     from plz4_amd import host
     from plz4_amd._native import Engine
@@ -182,6 +205,37 @@ def test_emu_hc_levels_4_to_11_on_the_lists(ref, orc, emu):
                 a, da = ref.compress_hc(src, cap, lvl)
                 b, db = emu.compress_hc_lists(src, cap, lvl)
                 assert a == b and np.array_equal(da, db), (name, src.size, lvl, cap, a, b)
+
+
+def _lazy_cases():
+    cases = [("T", synth.text(70000)), ("Z", np.zeros(9000, np.uint8)), ("M", synth.make("M", 140000, 65536)[60000:])]
+    cases += [(n, c[:6000]) for n, c in corpus.twin_cases()[:3]]
+    cases += [c for c in corpus.small_cases() if c[1].size in (0, 5, 12, 13, 14, 40, 300, 4097)]
+    cases += [("S%d" % s, corpus.structured(30000, s)) for s in range(2)]
+    rng = np.random.default_rng(7)
+    for it in range(5):
+        n = int(rng.integers(1000, 30000)); parts = []; have = 0
+        while have < n:
+            pat = rng.integers(0, 256, int(rng.integers(1, 5)), dtype=np.uint8)
+            parts += [np.tile(pat, int(rng.integers(1, 3000))), rng.integers(0, 256, int(rng.integers(0, 40)), dtype=np.uint8)]
+            have += parts[-1].size + parts[-2].size
+        cases.append(("P%d" % it, np.concatenate(parts)[:n].copy()))
+    return cases
+
+
+def test_emu_hc_lazy_levels_as_the_kernels_run_them(ref, orc, emu):
+    """Levels 3..9 for independent blocks (lz4hc_lazy_device.inl): searches one candidate per lane (levels 3..6, first searches
+    for 64 / attempts positions at once) or 63 per round (7..9), the deciding walk writing records, the block cut into
+    segments that are walked independently and stitched (one; few; many tiny ones: walks that meet late or not at all), the
+    emit stage of level 1 without catch-up == LZ4_compress_HC, for every capacity verdict."""
+    for name, src in _lazy_cases():
+        for lvl in range(3, 10):
+            caps = (orc.bound(src.size), src.size, max(src.size // 3, 1)) if lvl in (3, 5, 9) else (orc.bound(src.size),)
+            for cap in caps:
+                a, da = ref.compress_hc(src, cap, lvl)
+                for segs, mseg in ((1, 65536), (4, 8192), (16, 300)) if cap == caps[0] else ((3, 2000),):
+                    b, db = emu.compress_hc_lazy(src, cap, lvl, segs, mseg)
+                    assert a == b and np.array_equal(da, db), (name, src.size, lvl, cap, segs, mseg, a, b)
 
 
 # ---- level 12 in its three device phases (plz4_amd/csrc/lz4hc12_device.inl): chains + per-hash lists, F(p) per position, parser
