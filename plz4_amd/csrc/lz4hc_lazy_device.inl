@@ -1,12 +1,14 @@
-// lz4hc_lazy_device.inl -- HC levels 3..9 (the lazy hash-chain parser) for independent blocks, cut for a GPU: the waves that walk a
-// block only DECIDE -- searches with all 64 lanes, one 8-byte record per sequence; the block's bytes are written by the
-// data-parallel emit stage level 1 uses (lz4_seq_device.inl: one lane per sequence).
+// lz4hc_lazy_device.inl -- HC level 2 (LZ4MID) and levels 3..9 (the lazy hash-chain parser) for independent blocks, cut for a GPU:
+// the waves that walk a block only DECIDE -- searches with all 64 lanes, one 8-byte record per sequence; the block's bytes are
+// written by the data-parallel emit stage level 1 uses (lz4_seq_device.inl: one lane per sequence).
 //
 //   reference: /root/reference/internal/pkg/clz4/lz4hc.c
-//     LZ4HC_compress_hashChain :1121-1363 (nbSearches = 1 << (level-1), table :92-106; pattern analysis above 128 attempts)
-//     LZ4HC_InsertAndGetWiderMatch :884-1104, LZ4HC_encodeSequence :268-354, last literals :1330-1362
+//     levels 3..9  LZ4HC_compress_hashChain :1121-1363 (nbSearches = 1 << (level-1), table :92-106; pattern analysis above 128 attempts)
+//                  LZ4HC_InsertAndGetWiderMatch :884-1104
+//     level 2      LZ4MID_compress :521-775 (hc_mid_parse, at the end of this file)
+//     output       LZ4HC_encodeSequence :268-354, last literals :1330-1362 / :745-772
 //
-// What the reference's loop does, and where each part went:
+// Levels 3..9 -- what the reference's loop does, and where each part went:
 //   (1) Searches.  On an independent block every position below ip is in the chain when ip is searched (LZ4HC_Insert runs up to
 //       ip, :914), so the chain is a function of the data; it is built up front together with the per-hash lists
 //       (lz4hc12_device.inl: the candidates of a chain are consecutive list entries).  Levels 3..6 (4..32 attempts) search
@@ -329,6 +331,211 @@ DEV int hc_lazy_stitch(const uint8_t* __restrict__ src, int n, int level, HcWork
     }
     *lastAnchor = cur.anchor;
     return total;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- level 2
+// LZ4MID_compress (lz4hc.c:521-775) keeps two direct-mapped tables -- the last position inserted per hash of 4 bytes and of 7
+// bytes (:141-151) -- and inserts only the positions it searches (every position of a literal run, then two after a match's
+// start and four before its end, :678-706).  What a search finds therefore depends on the walk so far; but while the walk is in
+// a literal run it is easy to say what the tables WOULD hold if the run went on: every position searched so far inserted in
+// both.  hc_mid_parse takes the next positions of the run one per lane on exactly that assumption:
+//   * the three table entries a position may look at (its long hash, its short hash, and the long hash of the position behind
+//     it, :616) are read for all lanes at once -- one memory round trip instead of one per position;
+//   * a lane's candidate is the nearest lower lane of the batch with the same hash, else what the table held before the batch;
+//   * the first lane whose candidate matches ends the run: the lanes below it were literals, as assumed, so its own candidates
+//     are the true ones; the lanes above it were never searched and leave no trace.
+//   The lanes up to that one commit their inserts (the last lane of a hash stores), then the one sequence is handled as the
+//   reference does (the look at ip + 1, the catch-up, the table fills around the match), and the next batch starts behind it.
+// Batches are 4 lanes wide behind a match, then 16, then 64 in a literal run; the step between positions (:668: 1 + run length / 512)
+// is constant inside a batch.  The tables (128 KiB) live in device memory, per wave.  Output: records, as for levels 3..9.
+DEV uint32_t mid_hash4v(uint32_t v) { return (v * 2654435761u) >> (32 - 14); }
+DEV uint32_t mid_hash8v(uint64_t v) { return (uint32_t)(((v << 8) * 58295818150454627ull) >> (64 - 14)); }
+
+// Everything the sequence at a batch's matching lane needs measured, in ONE memory round trip: the match at P1 (distance D1)
+// forwards, the candidate of the look at ip + 1 (P2 = P1 + 1, distance D2, when alt) forwards, and both backwards (the catch-up,
+// :673-675, at most down to the anchor and to the block's start).  Lanes 0..23 / 24..47: eight bytes each of the two forward
+// counts; 48..55 / 56..63: eight bytes each backwards.  Longer ones go on with the whole wave.
+struct MidMeasure { int ml1, ml2, bk1, bk2; };
+DEV MidMeasure mid_measure(const uint8_t* __restrict__ src, int P1, int D1, bool alt, int P2, int D2, int anchor, int matchlimit)
+{
+    LV(int, cnt);
+    LANES({
+        const bool fwd = LANE < 48, second = fwd ? LANE >= 24 : LANE >= 56;
+        const int j = fwd ? (second ? LANE - 24 : LANE) : (second ? LANE - 56 : LANE - 48);
+        const int P = second ? P2 : P1, D = second ? D2 : D1;
+        int c = 0;
+        if (!second || alt) {
+            if (fwd) {
+                const int off = 8 * j, valid = (matchlimit - P) - off;
+                if (valid > 0) {
+                    uint64_t x = ld64p_guard(src + P + off, valid) ^ ld64p_guard(src + P - D + off, valid);
+                    if (valid < 8) x |= ~0ull << (8 * valid);
+                    c = x ? (ctz64(x) >> 3) : 8;
+                }
+            } else {
+                const int maxBack = min_(P - anchor, P - D), usable = maxBack - 8 * j;
+                if (usable >= 8) {
+                    const uint64_t x = ld64u(src + P - 8 * (j + 1)) ^ ld64u(src + P - D - 8 * (j + 1));
+                    c = x ? (int)(__builtin_clzll(x) >> 3) : 8;
+                } else for (; c < usable && src[P - 8 * j - 1 - c] == src[P - D - 8 * j - 1 - c]; ++c) {}
+            }
+        }
+        cnt[I_] = c;
+    })
+    const uint64_t stop = BALLOT(cnt[I_] < 8);
+    MidMeasure r;
+    auto part = [&](int lo, int nl) -> int {                     // 8 * full chunks + the first short one; -1: every chunk full
+        const uint64_t sm = (stop >> lo) & (((uint64_t)1 << nl) - 1);
+        if (!sm) return -1;
+        const int j0 = ctz64(sm);
+        return 8 * j0 + RL(cnt, lo + j0);
+    };
+    r.ml1 = part(0, 24);
+    if (r.ml1 < 0) r.ml1 = 192 + wave_count_ptr(src + P1 + 192, src + P1 - D1 + 192, (matchlimit - P1) - 192);
+    r.ml2 = 0; r.bk2 = 0;
+    if (alt) {
+        r.ml2 = part(24, 24);
+        if (r.ml2 < 0) r.ml2 = 192 + wave_count_ptr(src + P2 + 192, src + P2 - D2 + 192, (matchlimit - P2) - 192);
+        r.bk2 = part(56, 8);
+        if (r.bk2 < 0) r.bk2 = 64 + wave_back_ptr(src + P2 - 64, src + P2 - D2 - 64, min_(P2 - anchor, P2 - D2) - 64);
+    }
+    r.bk1 = part(48, 8);
+    if (r.bk1 < 0) r.bk1 = 64 + wave_back_ptr(src + P1 - 64, src + P1 - D1 - 64, min_(P1 - anchor, P1 - D1) - 64);
+    return r;
+}
+
+enum : int { kMidWidth0 = 4 };       // lanes of the batch right behind a match (text: a match every other position); then 16, then 64
+DEV int hc_mid_parse(const uint8_t* __restrict__ src, const int n, uint32_t* h4t, uint32_t* h8t, uint64_t* seq, int* lastAnchor)
+{
+    *lastAnchor = 0;
+    LANES({ for (int i = LANE; i < 16384; i += 64) { h4t[i] = 0u; h8t[i] = 0u; } })            // LZ4_initStreamHC: everything zero, lz4hc.c:1582-1583
+    WAVE_FENCE();
+    SeqSink out; out.seq = seq; out.n = 0;
+    LANES({ out.buf[I_] = 0; })
+    const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
+    const uint32_t ilimitIdx = (uint32_t)(n - 8) + kHcBase;
+    int ip = 0, anchor = 0, width = kMidWidth0;
+    if (n < kMinLength || ip > mflimit) { return 0; }
+
+    // a batch: the lanes' positions and their bytes (requested as soon as the batch's start is known: before the table fills of
+    // the sequence in front of it are made)
+    LV(int, pk); LV(bool, act); LV(uint64_t, a64); LV(uint64_t, b64);
+    int L = 0, step = 1;
+    auto fetch = [&]() {
+        const int run9 = (ip - anchor) >> 9;                                                   // :668: the step grows with the run
+        step = 1 + run9;
+        const int ip0 = ip, an = anchor, wd = width, st = step;
+        LANES({
+            pk[I_] = ip0 + LANE * st;
+            act[I_] = LANE < wd && pk[I_] <= mflimit && ((pk[I_] - an) >> 9) == run9;
+            a64[I_] = 0; b64[I_] = 0;
+            if (act[I_]) { a64[I_] = ld64u(src + pk[I_]); b64[I_] = ld64u(src + pk[I_] + 1); }
+        })
+        L = __builtin_popcountll(BALLOT(act[I_]));                                             // (lane 0 is in while ip <= mflimit)
+    };
+    fetch();
+    while (ip <= mflimit) {
+        // hashes and table entries
+        LV(uint32_t, h8); LV(uint32_t, h4); LV(uint32_t, h8x); LV(uint32_t, t8); LV(uint32_t, t4); LV(uint32_t, x8);
+        LANES({
+            h8[I_] = 0; h4[I_] = 0; h8x[I_] = 0; t8[I_] = 0; t4[I_] = 0; x8[I_] = 0;
+            if (act[I_]) {
+                h8[I_] = mid_hash8v(a64[I_]); h4[I_] = mid_hash4v((uint32_t)a64[I_]); h8x[I_] = mid_hash8v(b64[I_]);
+                t8[I_] = h8t[h8[I_]]; t4[I_] = h4t[h4[I_]]; x8[I_] = h8t[h8x[I_]];
+            }
+        })
+        // inside the batch: the nearest lower lane with the same hash takes the table's place; n8 / n4: the nearest HIGHER
+        // lane with a lane's hash (who stores, further down)
+        LV(int, n8); LV(int, n4);
+        LANES({ n8[I_] = 64; n4[I_] = 64; })
+        for (int i = 0; i < L; ++i) {
+            const uint32_t hi8 = RL(h8, i), hi4 = RL(h4, i);
+            const uint32_t idx = (uint32_t)(ip + i * step) + kHcBase;
+            const uint64_t above = ~(((uint64_t)2 << i) - 1);                                 // lanes > i (i == 63: none)
+            const uint64_t e8 = BALLOT(act[I_] && h8[I_] == hi8) & above;
+            const uint64_t e4 = BALLOT(act[I_] && h4[I_] == hi4) & above;
+            const int nx8 = e8 ? ctz64(e8) : 64, nx4 = e4 ? ctz64(e4) : 64;
+            LANES({
+                if ((e8 >> LANE) & 1) t8[I_] = idx;
+                if ((e4 >> LANE) & 1) t4[I_] = idx;
+                if (act[I_] && LANE >= i && h8x[I_] == hi8) x8[I_] = idx;                     // (a lane's own long insert comes before its look at ip + 1)
+                if (LANE == i) { n8[I_] = nx8; n4[I_] = nx4; }
+            })
+        }
+        // whose candidate matches (>= MINMATCH: four equal bytes, within 65535)
+        LV(bool, has8); LV(bool, has4);
+        LANES({
+            has8[I_] = false; has4[I_] = false;
+            if (act[I_]) {
+                const uint32_t idx = (uint32_t)pk[I_] + kHcBase;
+                if (idx - t8[I_] <= 65535u) has8[I_] = ld32u(src + (t8[I_] - kHcBase)) == (uint32_t)a64[I_];
+                if (idx - t4[I_] <= 65535u) has4[I_] = ld32u(src + (t4[I_] - kHcBase)) == (uint32_t)a64[I_];
+            }
+        })
+        const uint64_t hit = BALLOT(act[I_] && (has8[I_] || has4[I_]));
+        const int m = hit ? ctz64(hit) : L;
+        // the inserts of the lanes that were searched: the long table always (:575), the short one unless the long one matched (:604)
+        {
+            const int last8 = m < L ? m : L - 1;
+            const int last4 = (m < L && !RL(has8, m)) ? m : m - 1;
+            LANES({
+                const uint32_t idx = (uint32_t)pk[I_] + kHcBase;
+                if (LANE <= last8 && n8[I_] > last8) h8t[h8[I_]] = idx;
+                if (LANE <= last4 && n4[I_] > last4) h4t[h4[I_]] = idx;
+            })
+            LDS_ORDER();          // (the stores below may hit the same slots: they stay behind these, also for the compiler)
+        }
+        if (m >= L) { ip += L * step; width = width < 16 ? 16 : 64; if (ip <= mflimit) fetch(); continue; }
+
+        // ---- the sequence at lane m (:572-706)
+        int P = ip + m * step;
+        const uint32_t ipIndex = (uint32_t)P + kHcBase;
+        const bool via8 = RL(has8, m);
+        uint32_t dist = ipIndex - (via8 ? RL(t8, m) : RL(t4, m));
+        const uint32_t pos8 = RL(x8, m), m2d = ipIndex + 1 - pos8;
+        const bool alt = !via8 && m2d <= 65535u && pos8 >= kHcBase && P < mflimit;            // one look at ip + 1 for a longer one, :616-650
+        const MidMeasure mm = mid_measure(src, P, (int)dist, alt, P + 1, (int)m2d, anchor, matchlimit);
+        int ml = mm.ml1, back = mm.bk1;
+        if (alt && mm.ml2 > ml) {
+            const uint32_t hx = RL(h8x, m);
+            LANES({ if (LANE == 0) h8t[hx] = ipIndex + 1; })
+            LDS_ORDER();
+            P++; ml = mm.ml2; dist = m2d; back = mm.bk2;
+        }
+        P -= back; ml += back;                                                                 // :673-675
+        out.put(P, ml, (int)dist);
+        const int E = P + ml;
+        const uint32_t endIdx = (uint32_t)E + kHcBase;
+        const bool endOk = endIdx - 2 < ilimitIdx;                                             // :695
+        ip = E; anchor = E; width = kMidWidth0;
+        if (ip <= mflimit) fetch();                                                            // the next batch's bytes are on their way ...
+        {   // ... while the tables are filled around the match: two positions behind its start -- with the index of the search
+            // position although ip may have moved (:678-680) -- and four before its end (:695-706); one load each, the stores
+            // in the reference's order
+            LV(uint32_t, f8); LV(uint32_t, f4);
+            LANES({
+                const int at = LANE == 0 ? P + 1 : LANE == 1 ? P + 2 : LANE == 2 ? E - 5 : LANE == 3 ? E - 3 : LANE == 4 ? E - 2 : E - 1;
+                const bool on = LANE < 2 || (LANE < 6 && endOk && (LANE != 2 || E > 5));
+                uint64_t v = 0;
+                if (on) v = LANE == 5 ? (uint64_t)ld32u(src + at) : ld64u(src + at);
+                f8[I_] = mid_hash8v(v); f4[I_] = mid_hash4v((uint32_t)v);
+            })
+            // (one lane makes all of them: its own stores are ordered, two lanes' stores to one slot are not)
+            const uint32_t s0 = RL(f8, 0), s1 = RL(f8, 1), s2 = RL(f8, 2), s3 = RL(f8, 3), s4 = RL(f8, 4), q0 = RL(f4, 0), q4 = RL(f4, 4), q5 = RL(f4, 5);
+            const bool far = E > 5;
+            LANES({ if (LANE == 0) {
+                h8t[s0] = ipIndex + 1; h8t[s1] = ipIndex + 2; h4t[q0] = ipIndex + 1;
+                if (endOk) {
+                    if (far) h8t[s2] = endIdx - 5;
+                    h8t[s3] = endIdx - 3; h8t[s4] = endIdx - 2;
+                    h4t[q4] = endIdx - 2; h4t[q5] = endIdx - 1;
+                }
+            } })
+        }
+    }
+    out.finish();
+    *lastAnchor = anchor;
+    return out.n;
 }
 
 }  // namespace plz4

@@ -800,6 +800,21 @@ __global__ __launch_bounds__(256) void k_hc_gather(CodecArgs a)
     }
 }
 
+// Level 2 on independent blocks: the batch walk over the two tables (hc_mid_parse, lz4hc_lazy_device.inl), one wave per block,
+// the tables in the wave's slot of the HC workspace; records out, the emit kernels of level 1 behind it.
+__global__ __launch_bounds__(64) void k_hc_mid(CodecArgs a)
+{
+    uint32_t* const tabs = (uint32_t*)(a.hcWork + (size_t)blockIdx.x * kHcWorkBytes);
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int gi = a.blk0 + i;
+        const int n  = block_len(a, gi);
+        int lastAnchor = 0, nseq = -1;                                       // -1: a block the workspace was not sized for
+        if (n >= 0 && n <= a.l1MaxLen)
+            nseq = hc_mid_parse(a.src + (int64_t)gi * a.srcStride, n, tabs, tabs + 16384, a.l1Seq + (int64_t)i * a.l1SeqStride, &lastAnchor);
+        if ((threadIdx.x & 63u) == 0) { SeqInfo inf; inf.nseq = nseq; inf.lastAnchor = lastAnchor; inf.total = 0; inf.stored = 0; a.l1Info[i] = inf; }
+    }
+}
+
 // clz4.NewDictCtxHC (clz4.go:122-147): workgroup 0 builds the level-2 (lz4mid) tables of a dictionary, workgroup 1 the
 // hash-chain tables every other level shares.  tabs = 2 x kHcWorkBytes.
 __global__ __launch_bounds__(64) void k_hc_dict_prime(const uint8_t* dict, int len, uint8_t* tabs)
@@ -1197,11 +1212,21 @@ bool use_h12(const CodecArgs& a, int maxLen) { return a.level >= 12 && !a.hcEx &
 // levels 3..9, independent blocks up to 4 MiB: first searches ahead, deciding parser, record emit (lz4hc_lazy_device.inl)
 bool use_lazy(const CodecArgs& a, int maxLen) { return a.level >= 3 && a.level <= 9 && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_LAZY_OFF") == nullptr; }
 
+int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws, bool* midDeclined = nullptr);
+
 // Enqueue one HC call of nb blocks (a: everything but queue / workspace filled in) on s.  rawMode: LZ4 blocks, else records.
 int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode)
 {
     if (int rc = hc_enter(c, s)) return rc;
     hipError_t e;
+    if (a.level == 2 && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_MID_OFF") == nullptr) {
+        // level 2, independent blocks up to 4 MiB: the staged call of level 1 with the level-2 walk as its parser
+        if (int rc = ensure_hc(c)) return rc;
+        a.hcWork = c->d_hc;
+        bool declined = false;
+        if (int rc = launch_l1(c, s, a, nb, maxLen, rawMode, nullptr, &declined)) return rc;
+        if (!declined) return hc_leave(c, s);
+    }
     const bool lazy = use_lazy(a, maxLen);
     if (lazy || use_h12(a, maxLen)) {
         H12Plan pl;
@@ -1365,9 +1390,12 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
 // the memory set aside (half of what is free; PLZ4HIP_L1_BUDGET_GIB) runs in groups of equal size.  ws: the workspace to use
 // (a staging slot's own, always used from that slot's stream) or null for the ctx's, which is ordered across streams.
 // Larger blocks (raw block API only) and calls that do not say how long their blocks are keep the fused kernels.
-int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws)
+// midDeclined: the call is a level-2 call (k_hc_mid instead of k_l1_parse, records without catch-up); set when no workspace could
+// be had, the caller then runs its one-kernel path.
+int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws, bool* midDeclined)
 {
     hipError_t e;
+    const bool mid = midDeclined != nullptr;
     a.rawMode = rawMode; a.blk0 = 0; a.nBlocks = nb;
     const bool shared = (ws == nullptr);
     if (shared) ws = &c->l1;
@@ -1403,6 +1431,7 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         if (getenv("PLZ4HIP_VERBOSE"))
             fprintf(stderr, "plz4hip: level 1, %d blocks of <= %d: free %zu MiB, workspace %zu MiB, groups of %d%s\n", nb, maxLen, freeB >> 20, ws->bytes >> 20, per, fused ? " (fused)" : "");
     }
+    if (fused && mid) { *midDeclined = true; return PLZ4HIP_OK; }
     if (fused) {
         a.queue = next_queue(c, s, &e); HIPCHK(c, e);
         if (rawMode) ENC_LAUNCH(k_encode_raw, nb, c, s, a); else ENC_LAUNCH(k_encode_rec, nb, c, s, a);
@@ -1420,14 +1449,17 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         const int ng = nb - g0 < per ? nb - g0 : per;
         a.blk0 = g0; a.nBlocks = ng;
         a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-        ENC_LAUNCH(k_l1_parse, ng, c, s, a);
+        if (mid) hipLaunchKernelGGL(k_hc_mid, dim3(grid_for(ng, c->hcWaves)), dim3(64), 0, s, a);
+        else ENC_LAUNCH(k_l1_parse, ng, c, s, a);
         // emit: waves per block so that a small call still spreads over the chip
         int wg = (16384 / ng) / 4;
         if (wg > (maxChunks + 3) / 4) wg = (maxChunks + 3) / 4;
         if (wg < 1) wg = 1;
-        hipLaunchKernelGGL(k_l1_sizes<true>, dim3(wg, ng), dim3(256), 0, s, a);
+        if (mid) hipLaunchKernelGGL(k_l1_sizes<false>, dim3(wg, ng), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_l1_sizes<true>, dim3(wg, ng), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_l1_scan, dim3((ng + 3) / 4), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(k_l1_write<true>, dim3(wg, ng), dim3(256), 0, s, a);
+        if (mid) hipLaunchKernelGGL(k_l1_write<false>, dim3(wg, ng), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(k_l1_write<true>, dim3(wg, ng), dim3(256), 0, s, a);
         if (!rawMode && a.blockChecksum) hipLaunchKernelGGL(k_l1_finish, dim3((ng + 3) / 4), dim3(256), 0, s, a);
         HIPCHK(c, hipGetLastError());
     }

@@ -331,6 +331,22 @@ extern "C" int emu_compress_hc_lazy(const uint8_t* src, int n, uint8_t* dst, int
     return r;
 }
 
+// level 2 as the kernels run it for independent blocks: the batch walk over the two tables, records, emit
+extern "C" int emu_compress_hc_mid(const uint8_t* src, int n, uint8_t* dst, int cap)
+{
+    using namespace plz4;
+    if (n < 0 || n > kSeqMaxBlock) return -1;
+    uint8_t* padded = (uint8_t*)calloc((size_t)(n > 0 ? n : 0) + 64, 1);
+    if (n > 0) memcpy(padded, src, (size_t)n);
+    uint32_t* tabs = (uint32_t*)malloc(32768 * 4);
+    uint64_t* seq = (uint64_t*)malloc(((size_t)n / 4 + 64) * 8);
+    int lastAnchor = 0;
+    const int nseq = hc_mid_parse(padded, n, tabs, tabs + 16384, seq, &lastAnchor);
+    const int r = emu_emit_records(padded, n, seq, nseq, lastAnchor, dst, cap);
+    free(seq); free(tabs); free(padded);
+    return r;
+}
+
 // diagnostics of the level-1 parser's pipeline (see plz4_emu_cnt in lz4_seq_device.inl); reset on read
 extern "C" void emu_parse_counters(unsigned long long* out8)
 {

@@ -122,6 +122,14 @@ class Emu:
         r = int(self.L.emu_compress_hc_lazy(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, level, max_segs, min_seg))
         return r, dst[:max(r, 0)]
 
+    def compress_hc_mid(self, src, cap):
+        """Level 2 as the kernels run it: batches of a literal run over the two tables, records, emit (lz4hc_lazy_device.inl)."""
+        self.L.emu_compress_hc_mid.restype = C.c_int
+        self.L.emu_compress_hc_mid.argtypes = [u8p, C.c_int, u8p, C.c_int]
+        dst = np.zeros(max(cap, 1) + 64, dtype=np.uint8)
+        r = int(self.L.emu_compress_hc_mid(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap))
+        return r, dst[:max(r, 0)]
+
     def compress_hc_pre(self, src, cap, level):
         """HC levels 3..11 with the chain built up front (what the kernels run for independent blocks without dictionary)."""
         self.L.emu_compress_hc_pre.restype = C.c_int
