@@ -10,15 +10,15 @@
 //      :1802-1820, LZ4HC_Insert :781-802, pattern helpers :811-868, LZ4HC_countBack :202-225, price model :1778-1800,
 //      LZ4HC_encodeSequence :268-354.
 //
-// State of this file (round 3): the PARSERS here -- hc_compress_mid (level 2), hc_compress_chain (the lazy parser of levels 3..9),
-// hc_compress_opt (10..11; level 12 without dictionary has its own design in lz4hc12_device.inl) -- run as ONE logical thread per
-// block: all 64 lanes execute the same scalar program on uniform data (loads broadcast, stores coalesce), following the reference's
-// control flow decision for decision.  What is wave-parallel: the match finder of levels 4..11 (hc_find_wider_lists: up to 63
-// candidates of a chain per round, on the per-hash lists built up front by k_hc12_hist / k_hc12_chain), the chain itself (built
-// up front for levels 3..11, hc12_build_chain), match counting, chainSwap link reads, the optimal parser's price update.  With a
-// dictionary / linked blocks, and for blocks under 4 KiB, the tables (256 KiB hash + chain, 64 KiB prices) are built while
-// parsing, in a per-wave HBM workspace.  Levels 2 and 3 therefore run at the speed of one dependent instruction stream per block
-// (the row of SURVEY 8f that is still a port in shape).
+// State of this file (round 3).  Independent blocks without dictionary up to 4 MiB -- the frame path's blocks -- no longer run
+// the parsers of this file at levels 2..9 and 12: level 2 and levels 3..9 are lz4hc_lazy_device.inl (batches over the two
+// tables; segments walked at once, stitched; records through the emit stage of level 1), level 12 is lz4hc12_device.inl.  What
+// still runs here, as ONE logical thread per block (all 64 lanes execute the same scalar program on uniform data, following the
+// reference's control flow decision for decision): every level with a dictionary or linked blocks (hc_compress_mid,
+// hc_compress_chain, hc_compress_opt: the tables -- 256 KiB hash + chain, 64 KiB prices -- built while parsing, in a per-wave HBM
+// workspace), levels 10..11 (hc_compress_opt on the chain and lists built up front), and raw-API blocks above 4 MiB.  What is
+// wave-parallel in them: the match finder of levels 4..11 (hc_find_wider_lists: up to 63 candidates of a chain per round, also
+// what levels 7..9 of the new path search with), match counting, chainSwap link reads, the optimal parser's price update.
 //
 // Dictionaries and linked blocks (clz4.StreamCtxHC clz4.go:191-209, StreamLinkedCtxHC :250-283) come in the two
 // shapes LZ4_compress_HC_continue can take under plz4 (lz4hc.c:1438-1461, :1626-1720):

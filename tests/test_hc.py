@@ -242,12 +242,12 @@ def test_emu_hc_level2_in_batches(ref, orc, emu):
     """Level 2 for independent blocks (hc_mid_parse): the positions of a literal run one per lane on the assumption that the
     run goes on, candidates from the lanes below or the tables, the first matching lane ends the batch == LZ4_compress_HC(2).
     The pattern blocks repeat hashes inside a batch; the long random block takes the steps above 1 (:668)."""
-    cases = _lazy_cases() + [c for c in corpus.small_cases()]
-    cases += [("R", np.random.default_rng(3).integers(0, 256, 70000, dtype=np.uint8)), ("T2", synth.text(300000))]
+    cases = _lazy_cases() + [c for c in corpus.small_cases() if c[1].size <= 5000]
+    cases += [("R", np.random.default_rng(3).integers(0, 256, 40000, dtype=np.uint8)), ("T2", synth.text(120000))]
     mixed = np.concatenate([np.random.default_rng(4).integers(0, 256, 3000, dtype=np.uint8), synth.text(5000)] * 6)
     cases.append(("RT", mixed))
     for name, src in cases:
-        for cap in (orc.bound(src.size), src.size, max(src.size // 3, 1)):
+        for cap in (orc.bound(src.size), src.size, max(src.size // 3, 1)) if src.size <= 20000 else (orc.bound(src.size),):
             a, da = ref.compress_hc(src, cap, 2)
             b, db = emu.compress_hc_mid(src, cap)
             assert a == b and np.array_equal(da, db), (name, src.size, cap, a, b)
