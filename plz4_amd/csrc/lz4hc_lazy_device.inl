@@ -73,8 +73,10 @@ struct SeqSink {
 // is the first maximum.  Candidates: the entries below the position in its chain's list, while the chain has not ended, the
 // distance is <= 65535 (:918; a saturated link, :1065, leads below that window as well) and attempts are left.
 struct LzFound { int pos, len, off, back; };          // pos < 0: nothing
-DEV LzFound hc_find_few(const HcState& s, const int pos, const int low, const int highLimit, const int longest, const int nb,
-                        const bool multi, const int mflimit)
+// one round of at most 64 candidates: those ciBase.. below the position in its list; *more: every lane had a candidate (the chain
+// goes on below them).  len = the largest total of the round (0: none), first candidate first.
+DEV LzFound hc_find_round(const HcState& s, const int pos, const int low, const int highLimit, const int nb,
+                          const bool multi, const int mflimit, const int ciBase, bool* more)
 {
     const uint8_t* const src = s.src;
     const uint8_t* const iHigh = src + highLimit;
@@ -87,17 +89,19 @@ DEV LzFound hc_find_few(const HcState& s, const int pos, const int low, const in
         const bool act = multi ? p[I_] <= mflimit : LANE < nb;
         uint32_t head = 0, rk = 0;
         if (act) { head = s.w.pre[p[I_]]; rk = s.w.rank[p[I_]]; }
-        const int at = (int)rk - 1 - ci[I_];
+        const int at = (int)rk - 1 - ciBase - ci[I_];
         uint32_t e = 0x80000000u;
         if (act && head && at >= -8) e = s.w.list[at];
         q[I_] = (int)(e & 0x7FFFFFFFu);
         key[I_] = (act && head) ? (e >> 31) : 2u;             // for now: 1 = the chain's first position, 2 = no candidate here
     })
     const uint64_t firsts = BALLOT(key[I_] == 1u);
+    LV(bool, ok);
     LANES({
         const int g0 = multi ? LANE - ci[I_] : 0;               // my group's first lane
         const uint64_t below = firsts & (((uint64_t)1 << LANE) - 1) & ~(((uint64_t)1 << g0) - 1);   // chain ended at a nearer candidate
         const bool valid = key[I_] != 2u && !below && p[I_] - q[I_] <= 65535 && q[I_] < p[I_];
+        ok[I_] = valid && !((firsts >> LANE) & 1);                                                  // ... and the chain goes on below it
         int total = 0; bk[I_] = 0;
         if (valid) {
             const uint8_t* const ipp = src + p[I_];
@@ -115,8 +119,9 @@ DEV LzFound hc_find_few(const HcState& s, const int pos, const int low, const in
         LANES({ o[I_] = SHFL(key, LANE ^ m); })
         LANES({ key[I_] = key[I_] > o[I_] ? key[I_] : o[I_]; })
     }
-    LzFound f; f.pos = -1; f.len = longest; f.off = 0; f.back = 0;
-    const uint64_t hit = BALLOT(ci[I_] == 0 && (int)(key[I_] >> 6) > longest);
+    *more = BALLOT(ok[I_]) == ~0ull;
+    LzFound f; f.pos = -1; f.len = 0; f.off = 0; f.back = 0;
+    const uint64_t hit = BALLOT(ci[I_] == 0 && (key[I_] >> 6) != 0u);
     if (hit) {
         const int l0 = multi ? ctz64(hit) : 0;
         const uint32_t kk = RL(key, l0);
@@ -124,6 +129,18 @@ DEV LzFound hc_find_few(const HcState& s, const int pos, const int low, const in
         f.pos = RL(p, l0); f.len = (int)(kk >> 6); f.off = f.pos - RL(q, c); f.back = RL(bk, c);
     }
     return f;
+}
+DEV LzFound hc_find_few(const HcState& s, const int pos, const int low, const int highLimit, const int longest, const int nb,
+                        const bool multi, const int mflimit)
+{
+    bool more = false;
+    LzFound best = hc_find_round(s, pos, low, highLimit, nb < 64 ? nb : 64, multi, mflimit, 0, &more);
+    for (int base = 64; base < nb && more; base += 64) {                    // (128 attempts: a second round, for the one position)
+        const LzFound f = hc_find_round(s, pos, low, highLimit, nb - base < 64 ? nb - base : 64, false, mflimit, base, &more);
+        if (f.len > best.len) best = f;                                     // a later candidate replaces only when longer (:934)
+    }
+    if (best.len <= longest) { best.pos = -1; best.len = longest; best.off = 0; best.back = 0; }
+    return best;
 }
 
 // What a walk over part of a block leaves behind
@@ -155,7 +172,7 @@ DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int le
     LzRun run; run.cnt = 0; run.endIp = ipStart; run.finished = 1; run.anchor = ipStart;
     if (n < kMinLength) return run;                                                              // :1155
 
-    const bool few = maxNb <= 32;                                // levels 3..6: one candidate per lane, first searches in groups
+    const bool few = !pa;                                        // levels 3..8: one candidate per lane, first searches in groups of 64 / attempts
     auto wider = [&](int pos, int low, int longest) {
         if (few) { const LzFound f = hc_find_few(s, pos, low, matchlimit, longest, maxNb, false, mflimit); HcMatch m; m.len = f.len; m.off = f.off; m.back = f.back; return m; }
         return hc_find_wider_lists(s, pos, low, matchlimit, longest, maxNb, pa, false);
@@ -172,7 +189,7 @@ DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int le
             while (ip <= mflimit) {
                 if (few) {
                     const LzFound f = hc_find_few(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, true, mflimit);
-                    if (f.pos < 0) { ip += 64 / maxNb; continue; }
+                    if (f.pos < 0) { ip += maxNb < 64 ? 64 / maxNb : 1; continue; }
                     ip = f.pos; m1.len = f.len; m1.off = f.off; m1.back = 0;
                 } else {
                     m1 = wider(ip, ip, kMinMatch - 1);
