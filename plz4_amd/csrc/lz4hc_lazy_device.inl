@@ -75,13 +75,14 @@ struct SeqSink {
 struct LzFound { int pos, len, off, back; };          // pos < 0: nothing
 // one round of at most 64 candidates: those ciBase.. below the position in its list; *more: every lane had a candidate (the chain
 // goes on below them).  len = the largest total of the round (0: none), first candidate first.
+// *link1: a candidate of the round has a chain link of 1 (where level 9's pattern analysis would step in, :989).
 DEV LzFound hc_find_round(const HcState& s, const int pos, const int low, const int highLimit, const int nb,
-                          const bool multi, const int mflimit, const int ciBase, bool* more)
+                          const bool multi, const int mflimit, const int ciBase, bool* more, bool* link1)
 {
     const uint8_t* const src = s.src;
     const uint8_t* const iHigh = src + highLimit;
     const int lookBack = pos - low;
-    LV(int, p); LV(int, ci); LV(int, q); LV(uint32_t, key); LV(int, bk);
+    LV(int, p); LV(int, ci); LV(int, q); LV(uint32_t, key); LV(int, bk); LV(int, qn);
     LANES({
         const int g = multi ? LANE / nb : 0;
         ci[I_] = multi ? LANE % nb : LANE;
@@ -92,6 +93,7 @@ DEV LzFound hc_find_round(const HcState& s, const int pos, const int low, const 
         const int at = (int)rk - 1 - ciBase - ci[I_];
         uint32_t e = 0x80000000u;
         if (act && head && at >= -8) e = s.w.list[at];
+        qn[I_] = (link1 && act && head && at >= -7) ? (int)(s.w.list[at - 1] & 0x7FFFFFFFu) : -2;   // the entry below: this candidate's link
         q[I_] = (int)(e & 0x7FFFFFFFu);
         key[I_] = (act && head) ? (e >> 31) : 2u;             // for now: 1 = the chain's first position, 2 = no candidate here
     })
@@ -102,6 +104,7 @@ DEV LzFound hc_find_round(const HcState& s, const int pos, const int low, const 
         const uint64_t below = firsts & (((uint64_t)1 << LANE) - 1) & ~(((uint64_t)1 << g0) - 1);   // chain ended at a nearer candidate
         const bool valid = key[I_] != 2u && !below && p[I_] - q[I_] <= 65535 && q[I_] < p[I_];
         ok[I_] = valid && !((firsts >> LANE) & 1);                                                  // ... and the chain goes on below it
+        qn[I_] = (ok[I_] && q[I_] - qn[I_] == 1) ? 1 : 0;
         int total = 0; bk[I_] = 0;
         if (valid) {
             const uint8_t* const ipp = src + p[I_];
@@ -120,6 +123,7 @@ DEV LzFound hc_find_round(const HcState& s, const int pos, const int low, const 
         LANES({ key[I_] = key[I_] > o[I_] ? key[I_] : o[I_]; })
     }
     *more = BALLOT(ok[I_]) == ~0ull;
+    if (link1) *link1 = BALLOT(qn[I_] == 1) != 0;
     LzFound f; f.pos = -1; f.len = 0; f.off = 0; f.back = 0;
     const uint64_t hit = BALLOT(ci[I_] == 0 && (key[I_] >> 6) != 0u);
     if (hit) {
@@ -130,15 +134,20 @@ DEV LzFound hc_find_round(const HcState& s, const int pos, const int low, const 
     }
     return f;
 }
+// pa: level 9 (pattern analysis on).  Its walk is this one as long as no candidate it looks at has a link of 1; when one has,
+// pos = -2 comes back and the caller asks hc_find_wider_lists, which plays the pattern analysis.
 DEV LzFound hc_find_few(const HcState& s, const int pos, const int low, const int highLimit, const int longest, const int nb,
-                        const bool multi, const int mflimit)
+                        const bool multi, const int mflimit, const bool pa = false)
 {
-    bool more = false;
-    LzFound best = hc_find_round(s, pos, low, highLimit, nb < 64 ? nb : 64, multi, mflimit, 0, &more);
-    for (int base = 64; base < nb && more; base += 64) {                    // (128 attempts: a second round, for the one position)
-        const LzFound f = hc_find_round(s, pos, low, highLimit, nb - base < 64 ? nb - base : 64, false, mflimit, base, &more);
+    bool more = false, l1 = false, any1 = false;
+    LzFound best = hc_find_round(s, pos, low, highLimit, nb < 64 ? nb : 64, multi, mflimit, 0, &more, pa ? &l1 : nullptr);
+    any1 = l1;
+    for (int base = 64; base < nb && more && !any1; base += 64) {           // (128 / 256 attempts: more rounds, for the one position)
+        const LzFound f = hc_find_round(s, pos, low, highLimit, nb - base < 64 ? nb - base : 64, false, mflimit, base, &more, pa ? &l1 : nullptr);
+        any1 |= l1;
         if (f.len > best.len) best = f;                                     // a later candidate replaces only when longer (:934)
     }
+    if (any1) { best.pos = -2; best.len = longest; best.off = 0; best.back = 0; return best; }
     if (best.len <= longest) { best.pos = -1; best.len = longest; best.off = 0; best.back = 0; }
     return best;
 }
@@ -157,12 +166,14 @@ struct LzNoHook { DEVM bool operator()(int, int) const { return false; } };
 // the block ends).  w.pre / w.rank / w.list = the block's chain and lists.  hook(q, records so far) is called whenever a first
 // match has been found at q, before anything is decided about it; returning true ends the walk there (endIp = q).  Records go
 // to seq[0..).
-template <class Hook>
-DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
-                      const int ipStart, const int ipStop, Hook& hook)
+// kPa: level 9 (pattern analysis).  A template parameter so that the code of levels 3..8 does not carry the general finder (three
+// inlined copies of it cost levels 3..6 a quarter of their speed: instruction cache).
+template <bool kPa, class Hook>
+DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
+                        const int ipStart, const int ipStop, Hook& hook)
 {
     const int  maxNb = 1 << (level - 1);
-    const bool pa = maxNb > 128;
+    const bool pa = kPa;
     HcState s; s.src = src; s.pfx = 0; s.w = w; s.nextToUpdate = 0; s.d.mode = kHcNone; s.d.len = 0; s.d.bytes = nullptr; s.d.hash = nullptr; s.d.chain = nullptr;
     const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
     const int kOptimalMl = 15 - 1 + kMinMatch;                                                   // OPTIMAL_ML, lz4hc.c:75
@@ -172,10 +183,13 @@ DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int le
     LzRun run; run.cnt = 0; run.endIp = ipStart; run.finished = 1; run.anchor = ipStart;
     if (n < kMinLength) return run;                                                              // :1155
 
-    const bool few = !pa;                                        // levels 3..8: one candidate per lane, first searches in groups of 64 / attempts
+    // one candidate per lane (hc_find_few), first searches in groups of 64 / attempts; level 9 falls back to the general finder
+    // for the searches that meet a link of 1
     auto wider = [&](int pos, int low, int longest) {
-        if (few) { const LzFound f = hc_find_few(s, pos, low, matchlimit, longest, maxNb, false, mflimit); HcMatch m; m.len = f.len; m.off = f.off; m.back = f.back; return m; }
-        return hc_find_wider_lists(s, pos, low, matchlimit, longest, maxNb, pa, false);
+        const LzFound f = hc_find_few(s, pos, low, matchlimit, longest, maxNb, false, mflimit, pa);
+        if (kPa && f.pos == -2) return hc_find_wider_lists(s, pos, low, matchlimit, longest, maxNb, pa, false);
+        HcMatch m; m.len = f.len; m.off = f.off; m.back = f.back;
+        return m;
     };
 
     int st = kLzFirst;
@@ -187,13 +201,13 @@ DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int le
             bool found = false;
             if (ip >= ipStop && ip <= mflimit) { run.finished = 0; break; }
             while (ip <= mflimit) {
-                if (few) {
-                    const LzFound f = hc_find_few(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, true, mflimit);
+                const LzFound f = hc_find_few(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, true, mflimit, pa);
+                if (kPa && f.pos == -2) {                            // (level 9, a link of 1 among ip's candidates)
+                    m1 = hc_find_wider_lists(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, pa, false);
+                    if (m1.len < kMinMatch) { ip++; continue; }
+                } else {
                     if (f.pos < 0) { ip += maxNb < 64 ? 64 / maxNb : 1; continue; }
                     ip = f.pos; m1.len = f.len; m1.off = f.off; m1.back = 0;
-                } else {
-                    m1 = wider(ip, ip, kMinMatch - 1);
-                    if (m1.len < kMinMatch) { ip++; continue; }
                 }
                 found = true;
                 break;
@@ -277,6 +291,14 @@ DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int le
     out.finish();
     run.cnt = out.n; run.endIp = ip; run.anchor = anchor;
     return run;
+}
+
+template <class Hook>
+DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
+                      const int ipStart, const int ipStop, Hook& hook)
+{
+    if ((1 << (level - 1)) > 128) return hc_lazy_run_t<true>(src, n, level, w, seq, ipStart, ipStop, hook);      // pattern analysis above 128 attempts
+    return hc_lazy_run_t<false>(src, n, level, w, seq, ipStart, ipStop, hook);
 }
 
 // ---- segments.  Layout of a block's workspace (entries of 8 bytes): rec[j * segCap ..): the records of segment j;
