@@ -385,7 +385,9 @@ DEV int hc_lazy_stitch(const uint8_t* __restrict__ src, int n, int level, HcWork
 //     are the true ones; the lanes above it were never searched and leave no trace.
 //   The lanes up to that one commit their inserts (the last lane of a hash stores), then the one sequence is handled as the
 //   reference does (the look at ip + 1, the catch-up, the table fills around the match), and the next batch starts behind it.
-// Batches are 4 lanes wide behind a match, then 16, then 64 in a literal run; the step between positions (:668: 1 + run length / 512)
+// Batches are ONE lane wide behind a match (measured: 1 / 2 / 3 / 4 / 6 / 16 lanes = 7831 / 7684 / 7454 / 7245 / 6771 / 5395 MiB/s on
+// the T text, where a match starts every 10.6 bytes; measuring the one position's three candidates in the round trip of their
+// 4-byte test instead of after it: 7548, dropped), then 16, then 64 in a literal run; the step between positions (:668: 1 + run length / 512)
 // is constant inside a batch.  The tables (128 KiB) live in device memory, per wave.  Output: records, as for levels 3..9.
 DEV uint32_t mid_hash4v(uint32_t v) { return (v * 2654435761u) >> (32 - 14); }
 DEV uint32_t mid_hash8v(uint64_t v) { return (uint32_t)(((v << 8) * 58295818150454627ull) >> (64 - 14)); }
@@ -443,7 +445,10 @@ DEV MidMeasure mid_measure(const uint8_t* __restrict__ src, int P1, int D1, bool
     return r;
 }
 
-enum : int { kMidWidth0 = 4 };       // lanes of the batch right behind a match (text: a match every other position); then 16, then 64
+#ifndef PLZ4_MID_WIDTH0
+#define PLZ4_MID_WIDTH0 1
+#endif
+enum : int { kMidWidth0 = PLZ4_MID_WIDTH0 };       // lanes of the batch right behind a match (text: a match every other position); then 16, then 64
 DEV int hc_mid_parse(const uint8_t* __restrict__ src, const int n, uint32_t* h4t, uint32_t* h8t, uint64_t* seq, int* lastAnchor)
 {
     *lastAnchor = 0;

@@ -58,6 +58,19 @@ def main(iters=400, seed=7):
                     if a != b or not np.array_equal(da, db):
                         bad += 1
                         print("MISMATCH lists", it, kind, n, lvl, cap, a, b)
+                if 3 <= lvl <= 9:                        # round 3: segments walked at once and stitched, one candidate per lane, records + emit
+                    for segs, mseg in ((1, 65536), (16, 256 + 64 * (it % 9))):
+                        b, db = emu.compress_hc_lazy(src, cap, lvl, segs, mseg)
+                        tot += 1
+                        if a != b or not np.array_equal(da, db):
+                            bad += 1
+                            print("MISMATCH lazy", it, kind, n, lvl, cap, segs, mseg, a, b)
+                if lvl == 2:                             # round 3: level 2 in batches over its two tables
+                    b, db = emu.compress_hc_mid(src, cap)
+                    tot += 1
+                    if a != b or not np.array_equal(da, db):
+                        bad += 1
+                        print("MISMATCH mid", it, kind, n, cap, a, b)
                 if lvl == 12:                            # the three-phase level-12 path (lz4hc12_device.inl): chain, per-position search, parser
                     for nc, nl in ((0, 1024), (5, 48)):  # nc: positions left to the parser's own search; nl: price-table entries in "LDS"
                         b, db = emu.compress_hc12(src, cap, nc, nl)
