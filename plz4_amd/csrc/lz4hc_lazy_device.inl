@@ -160,7 +160,7 @@ struct LzRun {
     int anchor;
 };
 enum : int { kLzStarts = 64 };      // meeting points noted per segment
-struct LzNoHook { DEVM bool operator()(int, int) const { return false; } };
+struct LzNoHook { DEVM bool operator()(int, int, int) const { return false; } };
 
 // Levels 3..9 of an independent block, from state kLzFirst at ipStart until that state is reached again at or behind ipStop (or
 // the block ends).  w.pre / w.rank / w.list = the block's chain and lists.  hook(q, records so far) is called whenever a first
@@ -170,7 +170,7 @@ struct LzNoHook { DEVM bool operator()(int, int) const { return false; } };
 // inlined copies of it cost levels 3..6 a quarter of their speed: instruction cache).
 template <bool kPa, class Hook>
 DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
-                        const int ipStart, const int ipStop, Hook& hook)
+                        const int ipStart, const int anchorStart, const int ipStop, Hook& hook)
 {
     const int  maxNb = 1 << (level - 1);
     const bool pa = kPa;
@@ -179,8 +179,8 @@ DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int 
     const int kOptimalMl = 15 - 1 + kMinMatch;                                                   // OPTIMAL_ML, lz4hc.c:75
     SeqSink out; out.seq = seq; out.n = 0;
     LANES({ out.buf[I_] = 0; })
-    int ip = ipStart, anchor = ipStart;
-    LzRun run; run.cnt = 0; run.endIp = ipStart; run.finished = 1; run.anchor = ipStart;
+    int ip = ipStart, anchor = anchorStart;
+    LzRun run; run.cnt = 0; run.endIp = ipStart; run.finished = 1; run.anchor = anchorStart;
     if (n < kMinLength) return run;                                                              // :1155
 
     // one candidate per lane (hc_find_few), first searches in groups of 64 / attempts; level 9 falls back to the general finder
@@ -213,7 +213,7 @@ DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int 
                 break;
             }
             if (!found) break;
-            if (hook(ip, out.n)) { run.finished = 0; break; }
+            if (hook(ip, 0, out.n)) { run.finished = 0; break; }
             start0 = ip; m0 = m1;
             st = kLzSecond;
         }
@@ -293,12 +293,131 @@ DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int 
     return run;
 }
 
+// ---- levels 10..11: LZ4HC_compress_optimal (lz4hc.c:1823-2123) without the full update (:1406: level 12 only, which has its own
+// design, lz4hc12_device.inl).  The price DP over a window of up to 4096 positions is the reference's; its searches are wave-wide
+// (hc_find_wider_lists with the chain swap, 96 / 512 attempts: their length to beat, last_match_pos - cur, is walk state, so they
+// cannot be computed ahead like level 12's), its sequences are records, and it is walked in segments like the lazy levels.  One
+// difference: at the top of its loop (:1863) this parser's state is (ip, anchor) -- the literal run in front of a window enters
+// its prices (:1885-1894) -- so two walks have met when they find their next first match at the same position WITH the same anchor.
+template <class Hook>
+DEV LzRun hc_opt_run(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
+                     const int ipStart, const int anchorStart, const int ipStop, Hook& hook)
+{
+    const int nbSearches = level == 11 ? 512 : 96;                                               // table :92-106
+    const int sufficient = level == 11 ? 128 : 64;
+    HcOpt* const opt = w.opt;
+    HcState s; s.src = src; s.pfx = 0; s.w = w; s.nextToUpdate = 0; s.d.mode = kHcNone; s.d.len = 0; s.d.bytes = nullptr; s.d.hash = nullptr; s.d.chain = nullptr;
+    const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
+    SeqSink out; out.seq = seq; out.n = 0;
+    LANES({ out.buf[I_] = 0; })
+    int ip = ipStart, anchor = anchorStart;
+    LzRun run; run.finished = 1;
+    while (ip <= mflimit) {                                                                      // :1863
+        if (ip >= ipStop) { run.finished = 0; break; }
+        const int llen = ip - anchor;
+        int bestMl = 0, bestOff = 0, cur, last = 0;
+        const HcMatch first = hc_find_longer<false>(s, ip, matchlimit, kMinMatch - 1, nbSearches);
+        if (first.len == 0) { ip++; continue; }
+        if (hook(ip, anchor, out.n)) { run.finished = 0; break; }
+        if (first.len > sufficient) {                                                            // :1871-1882
+            out.put(ip, first.len, first.off);
+            ip += first.len; anchor = ip;
+            continue;
+        }
+        // the window's table from the first match (:1885-1919), one entry per lane
+        for (int i0 = 0; i0 <= first.len + kHcTrailing; i0 += 64) {
+            const int pm = hc_seq_price(llen, first.len);
+            LANES({
+                const int i = i0 + LANE;
+                HcOpt e;
+                if (i < kMinMatch) { e.mlen = 1; e.off = 0; e.litlen = llen + i; e.price = hc_lit_price(llen + i); opt[i] = e; }
+                else if (i <= first.len) { e.mlen = i; e.off = first.off; e.litlen = llen; e.price = hc_seq_price(llen, i); opt[i] = e; }
+                else if (i <= first.len + kHcTrailing) { e.mlen = 1; e.off = 0; e.litlen = i - first.len; e.price = pm + hc_lit_price(i - first.len); opt[i] = e; }
+            })
+        }
+        WAVE_FENCE();
+        last = first.len;
+        bool direct = false;
+        for (cur = 1; cur < last; ++cur) {                                                       // :1922-2019
+            const int curPos = ip + cur;
+            if (curPos > mflimit) break;
+            if (opt[cur + 1].price <= opt[cur].price) continue;                                  // :1932-1934 (no full update)
+            const HcMatch nm = hc_find_longer<false>(s, curPos, matchlimit, last - cur, nbSearches);
+            if (!nm.len) continue;
+            if (nm.len > sufficient || nm.len + cur >= kHcOptNum) {                              // :1948-1956
+                bestMl = nm.len; bestOff = nm.off; last = cur + 1; direct = true;
+                break;
+            }
+            {   const int baseLit = opt[cur].litlen;                                             // :1958-1972
+                for (int l = 1; l < kMinMatch; ++l) {
+                    const int price = opt[cur].price - hc_lit_price(baseLit) + hc_lit_price(baseLit + l);
+                    const int pos = cur + l;
+                    if (price < opt[pos].price) { opt[pos].mlen = 1; opt[pos].off = 0; opt[pos].litlen = baseLit + l; opt[pos].price = price; }
+                }
+            }
+            {   // every length of the match, one per lane (:1974-2009: each reads and writes its own entry; `last` moves at the last one)
+                const int ll = (opt[cur].mlen == 1) ? opt[cur].litlen : 0;
+                const int basePrice = (opt[cur].mlen == 1) ? ((cur > ll) ? opt[cur - ll].price : 0) : opt[cur].price;
+                const int lastOld = last;
+                for (int ml0 = kMinMatch; ml0 <= nm.len; ml0 += 64) {
+                    LV(int, took);
+                    LANES({
+                        const int ml = ml0 + LANE;
+                        took[I_] = 0;
+                        if (ml <= nm.len) {
+                            const int pos = cur + ml;
+                            const int price = basePrice + hc_seq_price(ll, ml);
+                            if (pos > lastOld + kHcTrailing || price <= opt[pos].price) {
+                                took[I_] = 1;
+                                opt[pos].mlen = ml; opt[pos].off = nm.off; opt[pos].litlen = ll; opt[pos].price = price;
+                            }
+                        }
+                    })
+                    if (nm.len - ml0 < 64) {
+                        const int lastLane = nm.len - ml0;
+                        if (RL(took, lastLane) && lastOld < cur + nm.len) last = cur + nm.len;
+                    }
+                }
+            }
+            for (int a = 1; a <= kHcTrailing; ++a) {                                             // :2011-2018
+                opt[last + a].mlen = 1; opt[last + a].off = 0; opt[last + a].litlen = a;
+                opt[last + a].price = opt[last].price + hc_lit_price(a);
+            }
+        }
+        if (!direct) { bestMl = opt[last].mlen; bestOff = opt[last].off; cur = last - bestMl; }   // :2022-2024
+        {   // the chosen path, marked backwards (:2026-2046) ...
+            int cand = cur, selML = bestMl, selOff = bestOff;
+            for (;;) {
+                const int nextML = opt[cand].mlen, nextOff = opt[cand].off;
+                opt[cand].mlen = selML; opt[cand].off = selOff;
+                selML = nextML; selOff = nextOff;
+                if (nextML > cand) break;
+                cand -= nextML;
+            }
+        }
+        {   // ... and its sequences in order (:2048-2064)
+            int r = 0;
+            while (r < last) {
+                const int ml = opt[r].mlen, off = opt[r].off;
+                if (ml == 1) { ip++; r++; continue; }
+                r += ml;
+                out.put(ip, ml, off);
+                ip += ml; anchor = ip;
+            }
+        }
+    }
+    out.finish();
+    run.cnt = out.n; run.endIp = ip; run.anchor = anchor;
+    return run;
+}
+
 template <class Hook>
 DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
-                      const int ipStart, const int ipStop, Hook& hook)
+                      const int ipStart, const int anchorStart, const int ipStop, Hook& hook)
 {
-    if ((1 << (level - 1)) > 128) return hc_lazy_run_t<true>(src, n, level, w, seq, ipStart, ipStop, hook);      // pattern analysis above 128 attempts
-    return hc_lazy_run_t<false>(src, n, level, w, seq, ipStart, ipStop, hook);
+    if (level >= 10) return hc_opt_run(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook);
+    if ((1 << (level - 1)) > 128) return hc_lazy_run_t<true>(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook);      // pattern analysis above 128 attempts
+    return hc_lazy_run_t<false>(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook);
 }
 
 // ---- segments.  Layout of a block's workspace (entries of 8 bytes): rec[j * segCap ..): the records of segment j;
@@ -315,11 +434,16 @@ DEV int lz_seg_len(int n, int segs) { return (n + segs - 1) / segs; }
 DEV int lz_seg_cap(int segLen) { return ((segLen / kMinMatch + 8) + 63) & ~63; }
 
 // pass 1, one wave per (block, segment)
+// a noted start: q (22 bits) | the anchor it was found with (22; 0 at the lazy levels, whose state does not hold it) | records before it (20)
+DEV uint64_t lz_start(int q, int anchor, int recs) { return ((uint64_t)(uint32_t)q << 42) | ((uint64_t)(uint32_t)anchor << 20) | (uint32_t)recs; }
+DEV int lz_start_q(uint64_t v) { return (int)(v >> 42); }
+DEV int lz_start_anchor(uint64_t v) { return (int)((v >> 20) & 0x3FFFFFu); }
+DEV int lz_start_recs(uint64_t v) { return (int)(v & 0xFFFFFu); }
 struct LzStartNote {
     uint64_t* starts; int n;
-    DEVM bool operator()(int q, int recs)
+    DEVM bool operator()(int q, int anchor, int recs)
     {
-        if (n < kLzStarts) { const uint64_t v = ((uint64_t)(uint32_t)q << 32) | (uint32_t)recs; const int at = n; LANES({ if (LANE == 0) starts[at] = v; }) ++n; }
+        if (n < kLzStarts) { const uint64_t v = lz_start(q, anchor, recs); const int at = n; LANES({ if (LANE == 0) starts[at] = v; }) ++n; }
         return false;
     }
 };
@@ -329,7 +453,7 @@ DEV void hc_lazy_segment(const uint8_t* __restrict__ src, int n, int level, HcWo
     const int segLen = lz_seg_len(n, segs), cap = lz_seg_cap(segLen);
     LzStartNote note; note.starts = starts + (size_t)j * kLzStarts; note.n = 0;
     const int b0 = j * segLen, b1 = j + 1 == segs ? n + 1 : (j + 1) * segLen;
-    const LzRun r = hc_lazy_run(src, n, level, w, rec + (size_t)j * cap, b0, b1, note);
+    const LzRun r = hc_lazy_run(src, n, level, w, rec + (size_t)j * cap, b0, b0, b1, note);
     const int ns = note.n;
     LANES({ if (LANE == 0) { meta[j].seg = r; meta[j].nStarts = ns; meta[j].skip = 0; meta[j].bridge.cnt = 0; } })
 }
@@ -337,10 +461,10 @@ DEV void hc_lazy_segment(const uint8_t* __restrict__ src, int n, int level, HcWo
 // pass 2, one wave per block: from where the walk before segment j truly ended to a meeting point with segment j
 struct LzMeet {
     const uint64_t* starts; int nStarts, at, skip, met;
-    DEVM bool operator()(int q, int)
+    DEVM bool operator()(int q, int anchor, int)
     {
-        while (at < nStarts && (int)(starts[at] >> 32) < q) ++at;
-        if (at < nStarts && (int)(starts[at] >> 32) == q) { met = 1; skip = (int)(uint32_t)starts[at]; return true; }
+        while (at < nStarts && lz_start_q(starts[at]) < q) ++at;
+        if (at < nStarts && lz_start_q(starts[at]) == q && lz_start_anchor(starts[at]) == anchor) { met = 1; skip = lz_start_recs(starts[at]); return true; }
         return false;
     }
 };
@@ -357,7 +481,7 @@ DEV int hc_lazy_stitch(const uint8_t* __restrict__ src, int n, int level, HcWork
         const int b1 = j + 1 == segs ? n + 1 : (j + 1) * segLen;
         if (!cur.finished && cur.endIp < b1) {
             LzMeet meet; meet.starts = starts + (size_t)j * kLzStarts; meet.nStarts = meta[j].nStarts; meet.at = 0; meet.skip = 0; meet.met = 0;
-            const LzRun br = hc_lazy_run(src, n, level, w, bridge + (size_t)j * cap, cur.endIp, b1, meet);
+            const LzRun br = hc_lazy_run(src, n, level, w, bridge + (size_t)j * cap, cur.endIp, cur.anchor, b1, meet);
             pb.cnt = br.cnt;
             total += br.cnt;
             if (meet.met) {                          // from here on segment j's walk is the true one

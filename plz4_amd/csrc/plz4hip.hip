@@ -749,6 +749,7 @@ __global__ __launch_bounds__(64) void k_hc12_parse(CodecArgs a)
 __device__ __forceinline__ HcWork lz_work(const CodecArgs& a, int g)
 {
     HcWork w; w.hash = nullptr; w.chain = nullptr; w.opt = nullptr; w.pre = nullptr; w.rank = nullptr; w.list = nullptr;
+    if (a.level >= 10) w.opt = hc_work_of(a).opt;                           // levels 10..11: the wave's price table (its slot of the HC workspace)
     return hc_with_pre(w, a, g);
 }
 __global__ __launch_bounds__(64) void k_hc_lazy(CodecArgs a)
@@ -1209,8 +1210,8 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl, bool lazy)
 
 // (blocks of 8 MiB and more -- raw block API only -- keep the one-thread-per-block kernel: the writer packs positions into 23 bits)
 bool use_h12(const CodecArgs& a, int maxLen) { return a.level >= 12 && !a.hcEx && maxLen < (1 << 23) && getenv("PLZ4HIP_HC12_OFF") == nullptr; }
-// levels 3..9, independent blocks up to 4 MiB: first searches ahead, deciding parser, record emit (lz4hc_lazy_device.inl)
-bool use_lazy(const CodecArgs& a, int maxLen) { return a.level >= 3 && a.level <= 9 && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_LAZY_OFF") == nullptr; }
+// levels 3..11, independent blocks up to 4 MiB: segments walked at once, stitched, record emit (lz4hc_lazy_device.inl)
+bool use_lazy(const CodecArgs& a, int maxLen) { return a.level >= 3 && a.level <= 11 && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_LAZY_OFF") == nullptr; }
 
 int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws, bool* midDeclined = nullptr);
 
@@ -1238,6 +1239,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         a.h12Ws = c->d_h12 + pl.offWs; a.h12Err = (int32_t*)(c->d_h12 + pl.offErr); c->h12ErrOff = pl.offErr;
         a.rawMode = rawMode;
         if (lazy) {
+            if (a.level >= 10) { if (int rc = ensure_hc(c)) return rc; a.hcWork = c->d_hc; }
             if (!c->hcLazyWaves) {
                 int per = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc_lazy, 64, 0) != hipSuccess || per < 1) per = 8;
@@ -1274,9 +1276,10 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
                 a.lzSegs = kLzMaxSegs;
                 if (const char* v = getenv("PLZ4HIP_HC_SEGS")) a.lzSegs = atoi(v);
                 a.lzSegs = a.lzSegs < 1 ? 1 : (a.lzSegs > kLzMaxSegs ? kLzMaxSegs : a.lzSegs);
-                hipLaunchKernelGGL(k_hc_lazy, dim3(grid_for(ng * a.lzSegs, c->hcLazyWaves)), dim3(64), 0, s, a);
+                const int lzWaves = a.level >= 10 && c->hcWaves < c->hcLazyWaves ? c->hcWaves : c->hcLazyWaves;   // (a price table per wave)
+                hipLaunchKernelGGL(k_hc_lazy, dim3(grid_for(ng * a.lzSegs, lzWaves)), dim3(64), 0, s, a);
                 a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-                hipLaunchKernelGGL(k_hc_stitch, dim3(grid_for(ng, c->hcLazyWaves)), dim3(64), 0, s, a);
+                hipLaunchKernelGGL(k_hc_stitch, dim3(grid_for(ng, lzWaves)), dim3(64), 0, s, a);
                 hipLaunchKernelGGL(k_hc_gather, dim3(ng >= 1024 ? 4 : 16, ng), dim3(256), 0, s, a);
                 int wg = (16384 / ng) / 4;                                  // emit: waves per block so that a small call still spreads over the chip
                 if (wg > (pl.maxChunks + 3) / 4) wg = (pl.maxChunks + 3) / 4;

@@ -313,7 +313,9 @@ extern "C" int emu_compress_hc_lazy(const uint8_t* src, int n, uint8_t* dst, int
     using namespace plz4;
     if (n < 0 || n > kSeqMaxBlock) return -1;
     H12Emu E(src, n);
-    HcWork w = emu_hc_work(nullptr);
+    static thread_local uint8_t* ows = nullptr;
+    if (!ows) ows = (uint8_t*)malloc(kHcWorkBytes);
+    HcWork w = emu_hc_work(ows);                      // (levels 10..11 keep their price table there)
     w.pre = E.chain; w.rank = E.rank; w.list = E.listBase + 8;
     // pass 1: every segment; pass 2: the bridges; pass 3: the pieces gathered into one array
     const int segs = lz_segments(n, maxSegs, minSeg), segCap = lz_seg_cap(lz_seg_len(n, segs));

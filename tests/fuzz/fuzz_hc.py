@@ -58,7 +58,7 @@ def main(iters=400, seed=7):
                     if a != b or not np.array_equal(da, db):
                         bad += 1
                         print("MISMATCH lists", it, kind, n, lvl, cap, a, b)
-                if 3 <= lvl <= 9:                        # round 3: segments walked at once and stitched, one candidate per lane, records + emit
+                if 3 <= lvl <= 11:                       # round 3: segments walked at once and stitched, one candidate per lane, records + emit
                     for segs, mseg in ((1, 65536), (16, 256 + 64 * (it % 9))):
                         b, db = emu.compress_hc_lazy(src, cap, lvl, segs, mseg)
                         tot += 1

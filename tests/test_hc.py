@@ -83,13 +83,13 @@ def test_gpu_hc_vs_reference(ref, orc):
 
 @pytest.mark.gpu
 def test_gpu_hc_lazy_levels_in_segments(ref, orc, monkeypatch):
-    """Levels 3..9 walk a block in segments at once and stitch the walks (lz4hc_lazy_device.inl).  Small segments in small
+    """Levels 3..11 walk a block in segments at once and stitch the walks (lz4hc_lazy_device.inl).  Small segments in small
     blocks: many stitches per block, walks that meet late or never (the pattern blocks); and the old one-wave path switched
     on instead (PLZ4HIP_HC_LAZY_OFF) still gives the same bytes."""
     from plz4_amd._native import Engine
     cases = [c for c in _cases() if c[1].size <= 150000] + [c for c in _lazy_cases() if c[0].startswith("P")]
     srcs = [s for _, s in cases]
-    want = {lvl: [ref.compress_hc(s, orc.bound(s.size), lvl) for s in srcs] for lvl in (3, 4, 6, 9)}
+    want = {lvl: [ref.compress_hc(s, orc.bound(s.size), lvl) for s in srcs] for lvl in (3, 4, 6, 9, 10, 11)}
     for env in ({"PLZ4HIP_HC_MIN_SEG": "2048", "PLZ4HIP_HC_SEGS": "16"}, {"PLZ4HIP_HC_MIN_SEG": "20000", "PLZ4HIP_HC_SEGS": "3"},
                 {"PLZ4HIP_HC_LAZY_OFF": "1"}):
         for k in ("PLZ4HIP_HC_MIN_SEG", "PLZ4HIP_HC_SEGS", "PLZ4HIP_HC_LAZY_OFF"):
@@ -97,7 +97,7 @@ def test_gpu_hc_lazy_levels_in_segments(ref, orc, monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = Engine(0)
-        for lvl in (3, 4, 6, 9):
+        for lvl in (3, 4, 6, 9, 10, 11):
             res, outs = eng.compress_batch(srcs, [orc.bound(s.size) for s in srcs], level=lvl)
             for (name, s), r, o, (a, da) in zip(cases, res, outs, want[lvl]):
                 assert int(r) == a and np.array_equal(o, da), (env, name, s.size, lvl)
@@ -229,8 +229,8 @@ def test_emu_hc_lazy_levels_as_the_kernels_run_them(ref, orc, emu):
     segments that are walked independently and stitched (one; few; many tiny ones: walks that meet late or not at all), the
     emit stage of level 1 without catch-up == LZ4_compress_HC, for every capacity verdict."""
     for name, src in _lazy_cases():
-        for lvl in range(3, 10):
-            caps = (orc.bound(src.size), src.size, max(src.size // 3, 1)) if lvl in (3, 5, 9) else (orc.bound(src.size),)
+        for lvl in range(3, 12):                          # 10, 11: the optimal parser in segments (walks meet on position AND anchor)
+            caps = (orc.bound(src.size), src.size, max(src.size // 3, 1)) if lvl in (3, 5, 9, 11) else (orc.bound(src.size),)
             for cap in caps:
                 a, da = ref.compress_hc(src, cap, lvl)
                 for segs, mseg in ((1, 65536), (4, 8192), (16, 300)) if cap == caps[0] else ((3, 2000),):
