@@ -401,7 +401,7 @@ def main():
         # level 12 is one ABI call of four kernels (hist, chain, search, parse; lz4hc12_device.inl): they are timed together
         # level 1 is one ABI call of five kernels (parse, sizes, scan, write, finish; lz4_seq_device.inl), timed together as well
         enc_kernel = "k_l1_parse+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if args.level == 1 else ("k_hc12_hist+k_hc12_chain+k_hc12_search+k_hc12_parse" if args.level >= 12 else
-                      ("k_hc12_hist+k_hc12_chain+k_hc_lazy+k_hc_stitch+k_hc_gather+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if 3 <= args.level <= 9 else
+                      ("k_hc12_hist+k_hc12_chain+k_hc_lazy+k_hc_stitch+k_hc_gather+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if 3 <= args.level <= 11 else
                        ("k_hc_mid+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if args.level == 2 else "k_encode_rec_hc")))
         ach_enc = (S + C_bytes) / (enc_ms * 1e-3) / 1e9
         ach_dec = (S + C_bytes) / (dec_ms * 1e-3) / 1e9
