@@ -1,4 +1,5 @@
-// lz4hc_lazy_device.inl -- HC level 2 (LZ4MID) and levels 3..9 (the lazy hash-chain parser) for independent blocks, cut for a GPU:
+// lz4hc_lazy_device.inl -- HC level 2 (LZ4MID), levels 3..9 (the lazy hash-chain parser) and 10..11 (the optimal parser without
+// the full update) for independent blocks, cut for a GPU:
 // the waves that walk a block only DECIDE -- searches with all 64 lanes, one 8-byte record per sequence; the block's bytes are
 // written by the data-parallel emit stage level 1 uses (lz4_seq_device.inl: one lane per sequence).
 //
@@ -6,15 +7,17 @@
 //     levels 3..9  LZ4HC_compress_hashChain :1121-1363 (nbSearches = 1 << (level-1), table :92-106; pattern analysis above 128 attempts)
 //                  LZ4HC_InsertAndGetWiderMatch :884-1104
 //     level 2      LZ4MID_compress :521-775 (hc_mid_parse, at the end of this file)
+//     levels 10..11 LZ4HC_compress_optimal :1823-2123 (hc_opt_run)
 //     output       LZ4HC_encodeSequence :268-354, last literals :1330-1362 / :745-772
 //
 // Levels 3..9 -- what the reference's loop does, and where each part went:
 //   (1) Searches.  On an independent block every position below ip is in the chain when ip is searched (LZ4HC_Insert runs up to
 //       ip, :914), so the chain is a function of the data; it is built up front together with the per-hash lists
-//       (lz4hc12_device.inl: the candidates of a chain are consecutive list entries).  Levels 3..6 (4..32 attempts) search
-//       with hc_find_few: one candidate per lane, and for the FIRST search of a sequence (:1159 -- it runs at every position
-//       of a literal run until one finds something) 64 / attempts consecutive positions at once: three memory round trips
-//       serve 16 positions at level 3.  Levels 7..9 search with hc_find_wider_lists (63 candidates per round, pattern analysis).
+//       (lz4hc12_device.inl: the candidates of a chain are consecutive list entries).  The searches are hc_find_few: one
+//       candidate per lane, and for the FIRST search of a sequence (:1159 -- it runs at every position of a literal run until
+//       one finds something) 64 / attempts consecutive positions at once: three memory round trips serve 16 positions at
+//       level 3; levels 7..9 take one / two / four rounds of 64 candidates for one position.  Level 9's pattern analysis can only
+//       step in at a candidate whose chain link is 1: a search that meets one is handed to hc_find_wider_lists (lz4hc_device.inl).
 //       [Computing the first search of EVERY position ahead of the walk, one position per lane over the whole chip -- level
 //       12's scheme -- was built and measured here as well and lost at every level: the positions inside matches are searched
 //       for nothing.]
