@@ -76,10 +76,8 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
         // the four source bytes of a step's 64 positions are requested four steps ahead: a step then costs its two LDS atomics
         // and its stores, not a memory round trip (one wave per CU runs this: nothing else would hide it)
         auto words = [&](LVREF(uint32_t, w), int b) { LANES({ const int p = b + LANE; w[I_] = p < nIns ? ld32u(src + p) : 0u; }) };
-        // A step is cut in two: `issue` sends its two LDS atomics, `finish` uses their answers.  The next step's atomics are
-        // issued BEFORE this step is finished (the LDS keeps a wave's operations in order, so the table sees the steps in
-        // sequence): the atomics' latency runs under the previous step's shuffles, tests and stores.
-        auto issue = [&](const int base, LVREF(uint32_t, w), LVREF(uint32_t, h), LVREF(uint32_t, prev), LVREF(uint32_t, slot), LVREF(int, act)) {
+        auto step = [&](const int base, LVREF(uint32_t, w)) {
+            LV(uint32_t, h); LV(uint32_t, prev); LV(uint32_t, slot); LV(int, act);
             LANES({
                 const int p = base + LANE;
                 act[I_] = 0; h[I_] = 0; prev[I_] = 0; slot[I_] = 0;
@@ -92,10 +90,7 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
                     }
                 }
             })
-            LDS_ORDER();             // (the answers are waited for where they are used; no fence: it would wait for the loads ahead too)
-        };
-        auto finish = [&](const int base, LVREF(uint32_t, h), LVREF(uint32_t, prev), LVREF(uint32_t, slot), LVREF(int, act)) {
-            if (base >= nPad) return;
+            LDS_ORDER();             // (the atomics' answers are waited for where they are used; no fence: it would wait for the loads ahead too)
             {   // in lane order, a lane whose predecessor is in this batch sits right behind it in the list
                 LV(uint32_t, ps);
                 LANES({ ps[I_] = SHFL(slot, (prev[I_] > (uint32_t)base) ? (int)(prev[I_] - 1u - (uint32_t)base) : LANE); })
@@ -128,17 +123,14 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
             })
         };
         LV(uint32_t, w0); LV(uint32_t, w1); LV(uint32_t, w2); LV(uint32_t, w3);
-        LV(uint32_t, hA); LV(uint32_t, pA); LV(uint32_t, sA); LV(int, aA);
-        LV(uint32_t, hB); LV(uint32_t, pB); LV(uint32_t, sB); LV(int, aB);
         words(w0, 0); words(w1, 64); words(w2, 128); words(w3, 192);
-        issue(0, w0, hA, pA, sA, aA);
         for (int base = 0; base < nPad; base += 256) {
             LV(uint32_t, n0); LV(uint32_t, n1); LV(uint32_t, n2); LV(uint32_t, n3);
             words(n0, base + 256); words(n1, base + 320); words(n2, base + 384); words(n3, base + 448);
-            issue(base + 64, w1, hB, pB, sB, aB);   finish(base, hA, pA, sA, aA);
-            issue(base + 128, w2, hA, pA, sA, aA);  finish(base + 64, hB, pB, sB, aB);
-            issue(base + 192, w3, hB, pB, sB, aB);  finish(base + 128, hA, pA, sA, aA);
-            issue(base + 256, n0, hA, pA, sA, aA);  finish(base + 192, hB, pB, sB, aB);
+            step(base, w0);
+            if (base + 64 < nPad) step(base + 64, w1);
+            if (base + 128 < nPad) step(base + 128, w2);
+            if (base + 192 < nPad) step(base + 192, w3);
             LANES({ w0[I_] = n0[I_]; w1[I_] = n1[I_]; w2[I_] = n2[I_]; w3[I_] = n3[I_]; })
         }
         LDS_FENCE();
