@@ -1,4 +1,4 @@
-# bash scripts/_lz.sh <level> <blocks> [ENV=VAL ...]
+# bash scripts/bench_level.sh <level> <blocks> [ENV=VAL ...]
 L=$1; B=$2; shift 2
 for kv in "$@"; do export "$kv"; done
 python bench.py --level $L --blocks $B --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/lz_tmp.json 2>gpurun_out/lz_tmp.err

@@ -1,4 +1,4 @@
-# kernel-trace only: bash scripts/_trace.sh <tag> <bench args>
+# kernel-trace only: bash scripts/kernel_trace.sh <tag> <bench args>
 cd /tmp && export TMPDIR=/tmp
 R=/root/repo
 TAG=$1; shift
