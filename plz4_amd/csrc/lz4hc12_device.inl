@@ -73,8 +73,8 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
     for (int half = 0; half < 2; ++half) {
         LANES({ for (int i = LANE; i < kHcHashEntries / 2; i += 64) { lastT[i] = 0u; curT[i] = offsets[half * (kHcHashEntries / 2) + i]; } })
         LDS_FENCE();
-        // the four source bytes of a step's 64 positions are requested four steps ahead: a step then costs its two LDS atomics
-        // and its stores, not a memory round trip (one wave per CU runs this: nothing else would hide it)
+        // the four source bytes of a step's 64 positions are requested steps ahead: a step then costs its two LDS atomics and
+        // its stores, not a memory round trip (one wave per CU runs this: nothing else would hide it)
         auto words = [&](LVREF(uint32_t, w), int b) { LANES({ const int p = b + LANE; w[I_] = p < nIns ? ld32u(src + p) : 0u; }) };
         auto step = [&](const int base, LVREF(uint32_t, w)) {
             LV(uint32_t, h); LV(uint32_t, prev); LV(uint32_t, slot); LV(int, act);
@@ -122,17 +122,28 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
                 } else if (p >= nIns && half == 0) chain[p] = 0;
             })
         };
-        LV(uint32_t, w0); LV(uint32_t, w1); LV(uint32_t, w2); LV(uint32_t, w3);
-        words(w0, 0); words(w1, 64); words(w2, 128); words(w3, 192);
-        for (int base = 0; base < nPad; base += 256) {
-            LV(uint32_t, n0); LV(uint32_t, n1); LV(uint32_t, n2); LV(uint32_t, n3);
-            words(n0, base + 256); words(n1, base + 320); words(n2, base + 384); words(n3, base + 448);
-            step(base, w0);
-            if (base + 64 < nPad) step(base + 64, w1);
-            if (base + 128 < nPad) step(base + 128, w2);
-            if (base + 192 < nPad) step(base + 192, w3);
-            LANES({ w0[I_] = n0[I_]; w1[I_] = n1[I_]; w2[I_] = n2[I_]; w3[I_] = n3[I_]; })
+        // Sixteen steps' words are in flight: loads and stores of a wave complete in order, so the wait for a word is also a wait
+        // for every store issued before its load -- the scattered list stores of the steps before, an L2 round trip each.  With
+        // four steps per group the group took one such round trip (877 cycles per step); with sixteen it is shared by sixteen.
+#define HC12_W16(F) F(0) F(1) F(2) F(3) F(4) F(5) F(6) F(7) F(8) F(9) F(10) F(11) F(12) F(13) F(14) F(15)
+#define HC12_DECL(k)  LV(uint32_t, w##k); LV(uint32_t, n##k);
+#define HC12_FIRST(k) words(w##k, 64 * k);
+#define HC12_NEXT(k)  words(n##k, base + 1024 + 64 * k);
+#define HC12_STEP(k)  if (base + 64 * k < nPad) step(base + 64 * k, w##k);
+#define HC12_MOVE(k)  LANES({ w##k[I_] = n##k[I_]; })
+        HC12_W16(HC12_DECL)
+        HC12_W16(HC12_FIRST)
+        for (int base = 0; base < nPad; base += 1024) {
+            HC12_W16(HC12_NEXT)
+            HC12_W16(HC12_STEP)
+            HC12_W16(HC12_MOVE)
         }
+#undef HC12_W16
+#undef HC12_DECL
+#undef HC12_FIRST
+#undef HC12_NEXT
+#undef HC12_STEP
+#undef HC12_MOVE
         LDS_FENCE();
     }
 }
