@@ -23,12 +23,15 @@
  * ctx per writer/reader for concurrency, one per device for several GPUs (section D).  plz4hip_last_error returns the
  * calling thread's own copy of the text (valid until that thread asks again).
  * Memory: the host-buffer calls keep their pinned host + device staging (up to 3 chunks of <= 4 GiB; one of <= 12 GiB at the HC
- * levels, which run a chunk at a time) and the HC levels their
- * workspaces between calls; plz4hip_ctx_trim gives them back.  The HC workspaces are sized by the call: levels 4..12 on
- * independent blocks keep 10 bytes per input byte of the blocks in flight (chains + per-hash lists; level 12 another 8) and may
- * take up to three quarters of the device memory that is free when the call arrives (half, at most 96 GiB, for level 3's
- * chain alone); a call whose blocks do not fit runs in groups.  A caller that needs the memory for itself allocates first or
- * sets PLZ4HIP_HC_BUDGET_GIB.
+ * levels, which run a chunk at a time), level 1 its sequence records (2.25 bytes per input byte of the largest group of blocks
+ * in one call, at most half of what is free: PLZ4HIP_L1_BUDGET_GIB) and the HC levels their workspaces between calls;
+ * plz4hip_ctx_trim gives them back.  The HC workspaces are sized by the call: on independent blocks levels 3..11 keep 14.5 bytes
+ * per input byte of the blocks in flight (chain, per-hash lists, sequence records of the segments), level 12 18, level 2 2.25, out
+ * of a quarter of the device memory that is free when the call arrives, at most 64 GiB; a call whose blocks do not fit runs in
+ * groups.  A caller that owns the GPU raises the budget with PLZ4HIP_HC_BUDGET_GIB (these kernels live on blocks in flight).
+ * Other environment switches, for tests and experiments only: PLZ4HIP_HC_SEGS / PLZ4HIP_HC_MIN_SEG (segments a block is walked
+ * in at levels 3..11, default 16 of at least 64 KiB), PLZ4HIP_HC_LAZY_OFF / PLZ4HIP_HC_MID_OFF / PLZ4HIP_HC12_OFF / PLZ4HIP_L1_FUSED
+ * (the one-kernel paths of rounds 1-2 instead), PLZ4HIP_HOST_CHUNK_MB, PLZ4HIP_VERBOSE.
  */
 #ifndef PLZ4HIP_H
 #define PLZ4HIP_H
