@@ -30,7 +30,7 @@
  * of a quarter of the device memory that is free when the call arrives, at most 64 GiB; a call whose blocks do not fit runs in
  * groups.  A caller that owns the GPU raises the budget with PLZ4HIP_HC_BUDGET_GIB (these kernels live on blocks in flight).
  * Other environment switches, for tests and experiments only: PLZ4HIP_HC_SEGS / PLZ4HIP_HC_MIN_SEG (segments a block is walked
- * in at levels 3..11, default 16 of at least 64 KiB), PLZ4HIP_HC_LAZY_OFF / PLZ4HIP_HC_MID_OFF / PLZ4HIP_HC12_OFF / PLZ4HIP_L1_FUSED
+ * in at levels 3..11, default up to 512 of at least 8 KiB), PLZ4HIP_HC_LAZY_OFF / PLZ4HIP_HC_MID_OFF / PLZ4HIP_HC12_OFF / PLZ4HIP_L1_FUSED
  * (the one-kernel paths of rounds 1-2 instead), PLZ4HIP_HOST_CHUNK_MB, PLZ4HIP_VERBOSE.
  */
 #ifndef PLZ4HIP_H

@@ -1137,7 +1137,7 @@ size_t hc_default_budget(size_t freeBytes) { const size_t q = freeBytes / 4, cap
 struct H12Plan { int64_t chainStride, fStride; size_t perBlock; int group; size_t offRank, offList, offOffsets, offF, offWs, offErr, total;
                  int maxChunks; size_t offInfo, offChunkB, offChunkO;       // (the emit stage's small arrays: levels 3..9)
                  int64_t recStride; size_t offRec, offBridge, offMeta, offStarts, offPieces; };   // (segments: levels 3..9)
-constexpr int kLzMaxSegs = 16;
+constexpr int kLzMaxSegs = 512;
 int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl, bool lazy)
 {
     pl->chainStride = (int64_t)round_up((size_t)maxLen + 1, 1024);
@@ -1250,7 +1250,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             a.l1ChunkBytes = (uint32_t*)(c->d_h12 + pl.offChunkB); a.l1ChunkOff = (uint32_t*)(c->d_h12 + pl.offChunkO);
             a.lzRec = (uint64_t*)(c->d_h12 + pl.offRec); a.lzBridge = (uint64_t*)(c->d_h12 + pl.offBridge); a.lzRecStride = pl.recStride;
             a.lzMeta = (LzSegMeta*)(c->d_h12 + pl.offMeta); a.lzStarts = (uint64_t*)(c->d_h12 + pl.offStarts); a.lzPieces = (LzPiece*)(c->d_h12 + pl.offPieces);
-            a.lzMinSeg = 65536;
+            a.lzMinSeg = 8192;
             if (const char* v = getenv("PLZ4HIP_HC_MIN_SEG")) { const int m = atoi(v); if (m >= 64) a.lzMinSeg = m; }     // tests: many segments in small blocks
         }
         a.h12Gather = 12; a.h12Idle = 16;
@@ -1271,8 +1271,10 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);
             if (!lazy) hipLaunchKernelGGL(k_hc12_parse, dim3(grid_for(ng, c->h12ParseWaves)), dim3(64), 0, s, a);
             else {
-                // segments per block: measured at 2048 blocks of 4 MiB, level 3: 4 -> 5525, 8 -> 6197, 16 -> 6403 MiB/s -- more
-                // walks than the chip holds waves still pay (they even out the segments' lengths)
+                // segments per block: as many as there are 8 KiB pieces, at most 512.  Measured at 4096 blocks of 4 MiB, level 3 /
+                // level 9: 16 segments 7522 / 4870, 32: 7734 / 4986, 64: 7908 / 5090, 128: 8071 / 5691, 256: 8279 / 5958, 512: 8602 /
+                // 6139, 1024: 8642 / 6159 MiB/s.  Far more walks than the chip holds waves: the queue hands neighbouring segments of
+                // one block to neighbouring waves, which then share the block's source and lists in L2, and short items even out.
                 a.lzSegs = kLzMaxSegs;
                 if (const char* v = getenv("PLZ4HIP_HC_SEGS")) a.lzSegs = atoi(v);
                 a.lzSegs = a.lzSegs < 1 ? 1 : (a.lzSegs > kLzMaxSegs ? kLzMaxSegs : a.lzSegs);
