@@ -599,15 +599,32 @@ struct Hc12Anywhere { static constexpr bool value = false; };
         if (i_ < w.nl) { Hc12Ent e_; e_.price = (pr); e_.litlen = (ll); e_.mloff = (mo); e_.pad = 0; w.ent[i_] = e_; } \
         else { w.gprice[i_ - w.nl] = (pr); w.glitlen[i_ - w.nl] = (ll); w.gmloff[i_ - w.nl] = (mo); } } while (0)
 
-// == LZ4HC_compress_optimal(nbSearches 16384, sufficient_len 4095, fullUpdate) + the last literals (:1823-2123) over the
-// search results F[0 .. n-12] (chain: for positions F does not cover).  Returns the compressed size or 0 (limitedOutput).
-DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap,
-                   const Hc12F* __restrict__ F, const uint16_t* __restrict__ chain, const Hc12Ws& w)
+// What a walk over part of a block leaves behind (the segments of lz4hc_lazy_device.inl)
+struct LzRun {
+    int cnt;        // records written
+    int endIp;      // where it stopped, at the top of the parser's loop (>= the stop position), unless ...
+    int finished;   // ... it reached the block's end: anchor = where the last literals start
+    int anchor;
+};
+struct Hc12NoHook { DEVM bool operator()(int, int, int) const { return false; } };
+
+// == LZ4HC_compress_optimal(nbSearches 16384, sufficient_len 4095, fullUpdate) (:1823-2123) over the search results
+// F[0 .. n-12] (chain: for positions F does not cover).
+//   kRec = false: the whole block, written to dst with the last literals; returns the compressed size or 0 (limitedOutput).
+//   kRec = true : a walk from the top of the parser's loop (:1863) at (ipStart, anchorStart) until that point is reached again at
+//                 or behind ipStop, its sequences as records in seqOut (lz4_seq_device.inl's format); hook(q, anchor, records)
+//                 is called when a window's first match has been found at q and may end the walk there; *run = how it ended.
+//                 The state at the top of the loop is (ip, anchor): the literal run in front of a window enters its prices.
+template <bool kRec, class Hook>
+DEV int hc12_walk(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap,
+                  const Hc12F* __restrict__ F, const uint16_t* __restrict__ chain, const Hc12Ws& w,
+                  uint64_t* seqOut, const int ipStart, const int anchorStart, const int ipStop, Hook& hook, LzRun* run)
 {
     if ((uint32_t)n > (uint32_t)kMaxInput) return 0;                                       // :1388
     const bool limited = cap < compress_bound(n);                                          // :1505-1508
     const int mflimit = n - kMfLimit;
-    int ip = 0, anchor = 0, op = 0, nseq = 0;
+    int ip = ipStart, anchor = anchorStart, op = 0, nseq = 0, outN = 0;
+    bool finished = true;
     STAT_DECL;                              // diagnostics build only: cycles per part of the parser (scripts/stats_probe12.py)
     const unsigned long long tP0 = STAT_NOW(); (void)tP0;
 
@@ -638,6 +655,19 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         LDS_ORDER();
         const int cnt = nseq, anchor0 = anchor, op0 = op;
         nseq = 0;
+        if (kRec) {                                    // records: position, length - 4, offset (22 | 22 | 16 bits)
+            const int base = outN;
+            LANES({
+                if (LANE < cnt) {
+                    const uint64_t e = w.seq[LANE];
+                    seqOut[base + LANE] = (e & 0x3FFFFFu) | ((((e >> 23) & 0x7FFFFFu) - kMinMatch) << 22) | ((e >> 46) << 44);
+                }
+            })
+            outN += cnt;
+            const uint64_t le = UNI(w.seq[cnt - 1]);
+            anchor = (int)(le & 0x7FFFFFu) + (int)((le >> 23) & 0x7FFFFFu);
+            return true;
+        }
         LV(int, sp); LV(int, sm); LV(int, so); LV(int, an); LV(int, lit); LV(int, xl); LV(int, xm); LV(int, acc); LV(int, sz);
         LANES({
             sp[I_] = 0; sm[I_] = 0; so[I_] = 0; an[I_] = 0; lit[I_] = 0; xl[I_] = 0; xm[I_] = 0; sz[I_] = 0;
@@ -707,9 +737,10 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         return nseq < 64 ? true : flush();
     };
     // the position parsing has reached but not yet written up to (== `anchor` once the pending sequences are out)
-    int pendEnd = 0;
+    int pendEnd = anchorStart;
 
     while (ip <= mflimit) {                                                                // :1863
+        if (kRec && ip >= ipStop) { finished = false; break; }
         // ---- the next position with a match: F.len != 0 (positions without one only move ip, :1868)
         const unsigned long long tA = STAT_NOW(); (void)tA;
         f_window(ip);
@@ -723,6 +754,7 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         Hc12F first; first.len = RL(fLen, ip - fBase); first.off = RL(fOff, ip - fBase);
         if (first.len == kHc12NotComputed) first = search_now(ip);
         if (first.len == 0) { ip++; continue; }
+        if (kRec && hook(ip, pendEnd, outN + nseq)) { finished = false; break; }
         const int llen = ip - pendEnd;
         PSTAT(0, STAT_NOW() - tA);
         const unsigned long long tB = STAT_NOW(); (void)tB;
@@ -942,6 +974,10 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
         PSTAT(4, STAT_NOW() - tE);
     }
     if (!flush()) return 0;
+    if (kRec) {
+        run->cnt = outN; run->endIp = ip; run->finished = finished ? 1 : 0; run->anchor = pendEnd;
+        return outN;
+    }
     // last literals (:2067-2098, limitedOutput / notLimited)
     {
         const int lastRun = n - anchor;
@@ -955,6 +991,12 @@ DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __rest
     PSTAT(8, STAT_NOW() - tP0); PSTAT(11, 1);
     PSTAT_FLUSH();
     return op;
+}
+DEV int hc12_parse(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap,
+                   const Hc12F* __restrict__ F, const uint16_t* __restrict__ chain, const Hc12Ws& w)
+{
+    Hc12NoHook none;
+    return hc12_walk<false>(src, n, dst, cap, F, chain, w, nullptr, 0, 0, n + 1, none, nullptr);
 }
 
 }  // namespace plz4

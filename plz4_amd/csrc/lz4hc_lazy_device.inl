@@ -155,13 +155,6 @@ DEV LzFound hc_find_few(const HcState& s, const int pos, const int low, const in
     return best;
 }
 
-// What a walk over part of a block leaves behind
-struct LzRun {
-    int cnt;        // records written
-    int endIp;      // where it stopped, in state kLzFirst (>= the stop position), unless ...
-    int finished;   // ... it reached the block's end: anchor = where the last literals start
-    int anchor;
-};
 enum : int { kLzStarts = 64 };      // meeting points noted per segment
 struct LzNoHook { DEVM bool operator()(int, int, int) const { return false; } };
 
@@ -450,15 +443,22 @@ struct LzStartNote {
         return false;
     }
 };
-DEV void hc_lazy_segment(const uint8_t* __restrict__ src, int n, int level, HcWork w, int segs, int j,
-                         uint64_t* rec, LzSegMeta* meta, uint64_t* starts)
+// run(seq, ipStart, anchorStart, ipStop, hook) -> LzRun: the level's walk (hc_lazy_run; level 12: hc12_walk<true>)
+template <class Run>
+DEV void lz_segment(Run& run, int n, int segs, int j, uint64_t* rec, LzSegMeta* meta, uint64_t* starts)
 {
     const int segLen = lz_seg_len(n, segs), cap = lz_seg_cap(segLen);
     LzStartNote note; note.starts = starts + (size_t)j * kLzStarts; note.n = 0;
     const int b0 = j * segLen, b1 = j + 1 == segs ? n + 1 : (j + 1) * segLen;
-    const LzRun r = hc_lazy_run(src, n, level, w, rec + (size_t)j * cap, b0, b0, b1, note);
+    const LzRun r = run(rec + (size_t)j * cap, b0, b0, b1, note);
     const int ns = note.n;
     LANES({ if (LANE == 0) { meta[j].seg = r; meta[j].nStarts = ns; meta[j].skip = 0; meta[j].bridge.cnt = 0; } })
+}
+DEV void hc_lazy_segment(const uint8_t* __restrict__ src, int n, int level, HcWork w, int segs, int j,
+                         uint64_t* rec, LzSegMeta* meta, uint64_t* starts)
+{
+    auto run = [&](uint64_t* seq, int ipStart, int anchorStart, int ipStop, auto& hook) { return hc_lazy_run(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook); };
+    lz_segment(run, n, segs, j, rec, meta, starts);
 }
 
 // pass 2, one wave per block: from where the walk before segment j truly ended to a meeting point with segment j
@@ -472,8 +472,8 @@ struct LzMeet {
     }
 };
 // pieces[0 .. 2*segs): what the block's records are, in order; returns their total, *lastAnchor as the one walk's
-DEV int hc_lazy_stitch(const uint8_t* __restrict__ src, int n, int level, HcWork w, int segs,
-                       uint64_t* rec, uint64_t* bridge, LzSegMeta* meta, const uint64_t* starts, LzPiece* pieces, int* lastAnchor)
+template <class Run>
+DEV int lz_stitch(Run& run, int n, int segs, uint64_t* rec, uint64_t* bridge, LzSegMeta* meta, const uint64_t* starts, LzPiece* pieces, int* lastAnchor)
 {
     const int segLen = lz_seg_len(n, segs), cap = lz_seg_cap(segLen);
     LzRun cur = meta[0].seg;                      // the true walk so far ends like this
@@ -484,7 +484,7 @@ DEV int hc_lazy_stitch(const uint8_t* __restrict__ src, int n, int level, HcWork
         const int b1 = j + 1 == segs ? n + 1 : (j + 1) * segLen;
         if (!cur.finished && cur.endIp < b1) {
             LzMeet meet; meet.starts = starts + (size_t)j * kLzStarts; meet.nStarts = meta[j].nStarts; meet.at = 0; meet.skip = 0; meet.met = 0;
-            const LzRun br = hc_lazy_run(src, n, level, w, bridge + (size_t)j * cap, cur.endIp, cur.anchor, b1, meet);
+            const LzRun br = run(bridge + (size_t)j * cap, cur.endIp, cur.anchor, b1, meet);
             pb.cnt = br.cnt;
             total += br.cnt;
             if (meet.met) {                          // from here on segment j's walk is the true one
@@ -497,6 +497,33 @@ DEV int hc_lazy_stitch(const uint8_t* __restrict__ src, int n, int level, HcWork
     }
     *lastAnchor = cur.anchor;
     return total;
+}
+DEV int hc_lazy_stitch(const uint8_t* __restrict__ src, int n, int level, HcWork w, int segs,
+                       uint64_t* rec, uint64_t* bridge, LzSegMeta* meta, const uint64_t* starts, LzPiece* pieces, int* lastAnchor)
+{
+    auto run = [&](uint64_t* seq, int ipStart, int anchorStart, int ipStop, auto& hook) { return hc_lazy_run(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook); };
+    return lz_stitch(run, n, segs, rec, bridge, meta, starts, pieces, lastAnchor);
+}
+// level 12 (lz4hc12_device.inl): its price DP over the search results F, walked in segments the same way
+DEV void hc12_segment(const uint8_t* __restrict__ src, int n, const Hc12F* F, const uint16_t* chain, const Hc12Ws& w, int segs, int j,
+                      uint64_t* rec, LzSegMeta* meta, uint64_t* starts)
+{
+    auto run = [&](uint64_t* seq, int ipStart, int anchorStart, int ipStop, auto& hook) {
+        LzRun r; r.cnt = 0; r.endIp = ipStart; r.finished = 1; r.anchor = anchorStart;
+        hc12_walk<true>(src, n, nullptr, 0, F, chain, w, seq, ipStart, anchorStart, ipStop, hook, &r);
+        return r;
+    };
+    lz_segment(run, n, segs, j, rec, meta, starts);
+}
+DEV int hc12_stitch(const uint8_t* __restrict__ src, int n, const Hc12F* F, const uint16_t* chain, const Hc12Ws& w, int segs,
+                    uint64_t* rec, uint64_t* bridge, LzSegMeta* meta, const uint64_t* starts, LzPiece* pieces, int* lastAnchor)
+{
+    auto run = [&](uint64_t* seq, int ipStart, int anchorStart, int ipStop, auto& hook) {
+        LzRun r; r.cnt = 0; r.endIp = ipStart; r.finished = 1; r.anchor = anchorStart;
+        hc12_walk<true>(src, n, nullptr, 0, F, chain, w, seq, ipStart, anchorStart, ipStop, hook, &r);
+        return r;
+    };
+    return lz_stitch(run, n, segs, rec, bridge, meta, starts, pieces, lastAnchor);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- level 2

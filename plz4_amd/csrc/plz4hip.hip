@@ -801,6 +801,60 @@ __global__ __launch_bounds__(256) void k_hc_gather(CodecArgs a)
     }
 }
 
+// Level 12 up to 4 MiB: its parser (the price DP over F, lz4hc12_device.inl) walked in segments and stitched like levels 3..11,
+// records out.  The price table's LDS part is 256 entries here (4 KiB: windows beyond that spill to the wave's global slot), so
+// that registers, not LDS, bound the waves per CU.
+constexpr int kH12SegLds = 256;
+__device__ __forceinline__ Hc12Ws h12_seg_ws(const CodecArgs& a, Hc12Ent* ent, uint64_t* seqs)
+{
+    Hc12Ws w; w.ent = ent; w.nl = kH12SegLds; w.seq = seqs;
+    uint8_t* gws = a.h12Ws + (size_t)blockIdx.x * kHc12WsGlobalBytes;
+    w.gprice = (int*)gws; w.glitlen = (int*)(gws + kHc12OptEntries * 4); w.gmloff = (uint32_t*)(gws + kHc12OptEntries * 8);
+    return w;
+}
+__global__ __launch_bounds__(64) void k_hc12_seg(CodecArgs a)
+{
+    __shared__ Hc12Ent oEnt[kH12SegLds];
+    __shared__ uint64_t seqs[64];
+    const Hc12Ws w = h12_seg_ws(a, oEnt, seqs);
+    const int items = a.nBlocks * a.lzSegs;
+    const bool broken = plz4_readfirstlane(*(volatile int32_t*)a.h12Err) != 0;
+    for (int it = next_block(a.queue); it < items; it = next_block(a.queue)) {
+        const int g = it / a.lzSegs, j = it - g * a.lzSegs;
+        const int i = a.blk0 + g;
+        const int n = block_len(a, i);
+        if (broken || n < 0 || n > a.l1MaxLen) continue;
+        const int segs = lz_segments(n, a.lzSegs, a.lzMinSeg);
+        if (j >= segs) continue;
+        hc12_segment(a.src + (int64_t)i * a.srcStride, n, a.h12F + (int64_t)g * a.h12FStride, a.h12Chain + (int64_t)g * a.h12ChainStride, w, segs, j,
+                     a.lzRec + (int64_t)g * a.lzRecStride, a.lzMeta + (int64_t)g * a.lzSegs, a.lzStarts + (int64_t)g * a.lzSegs * kLzStarts);
+    }
+}
+__global__ __launch_bounds__(64) void k_hc12_stitch(CodecArgs a)
+{
+    __shared__ Hc12Ent oEnt[kH12SegLds];
+    __shared__ uint64_t seqs[64];
+    const Hc12Ws w = h12_seg_ws(a, oEnt, seqs);
+    const bool broken = plz4_readfirstlane(*(volatile int32_t*)a.h12Err) != 0;
+    for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
+        const int i = a.blk0 + g;
+        const int n = block_len(a, i);
+        LzPiece* const pieces = a.lzPieces + (int64_t)g * 2 * a.lzSegs;
+        int lastAnchor = 0, nseq = -1, segs = 0;
+        if (broken) nseq = kSeqEngineFailed;                                 // the search kernel gave up (spin guard): its F is not to be trusted
+        else if (n >= 0 && n <= a.l1MaxLen) {
+            segs = lz_segments(n, a.lzSegs, a.lzMinSeg);
+            nseq = hc12_stitch(a.src + (int64_t)i * a.srcStride, n, a.h12F + (int64_t)g * a.h12FStride, a.h12Chain + (int64_t)g * a.h12ChainStride, w, segs,
+                               a.lzRec + (int64_t)g * a.lzRecStride, a.lzBridge + (int64_t)g * a.lzRecStride,
+                               a.lzMeta + (int64_t)g * a.lzSegs, a.lzStarts + (int64_t)g * a.lzSegs * kLzStarts, pieces, &lastAnchor);
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            for (int k = 2 * segs; k < 2 * a.lzSegs; ++k) pieces[k].cnt = 0;
+            SeqInfo inf; inf.nseq = nseq; inf.lastAnchor = lastAnchor; inf.total = 0; inf.stored = 0; a.l1Info[g] = inf;
+        }
+    }
+}
+
 // Level 2 on independent blocks: the batch walk over the two tables (hc_mid_parse, lz4hc_lazy_device.inl), one wave per block,
 // the tables in the wave's slot of the HC workspace; records out, the emit kernels of level 1 behind it.
 __global__ __launch_bounds__(64) void k_hc_mid(CodecArgs a)
@@ -974,7 +1028,7 @@ struct plz4hip_ctx {
     HostSlot     slot[kSlots];
     uint8_t*     d_hc = nullptr;   int hcWaves = 0;     // HC workspace, one slot per resident HC wave (allocated on first use)
     // level 12 in three phases: chain + search results of one group of blocks, the parser's table overflow, an error flag
-    uint8_t*     d_h12 = nullptr;  size_t h12Bytes = 0;  int h12ParseWaves = 0;  int hcLazyWaves = 0;  size_t h12ErrOff = 0;
+    uint8_t*     d_h12 = nullptr;  size_t h12Bytes = 0;  int h12ParseWaves = 0;  int h12SegWaves = 0;  int hcLazyWaves = 0;  size_t h12ErrOff = 0;
     // Both HC workspaces belong to one job at a time: the stream of the last HC job and an event recorded behind it; an HC
     // job on another stream waits for that event on the device (no host block).
     hipEvent_t   hcDone = nullptr; hipStream_t hcStream = nullptr; bool hcPending = false;
@@ -1138,11 +1192,11 @@ struct H12Plan { int64_t chainStride, fStride; size_t perBlock; int group; size_
                  int maxChunks; size_t offInfo, offChunkB, offChunkO;       // (the emit stage's small arrays: levels 3..9)
                  int64_t recStride; size_t offRec, offBridge, offMeta, offStarts, offPieces; };   // (segments: levels 3..9)
 constexpr int kLzMaxSegs = 512;
-int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl, bool lazy)
+int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl, bool lazy, bool needF)
 {
     pl->chainStride = (int64_t)round_up((size_t)maxLen + 1, 1024);
     pl->fStride = (int64_t)round_up((size_t)(maxLen > 11 ? maxLen - 11 : 1), 64);
-    if (lazy) pl->fStride = (int64_t)round_up((size_t)maxLen / 4 + 64, 64);          // no search results there: only the block's final records
+    if (!needF) pl->fStride = (int64_t)round_up((size_t)maxLen / 4 + 64, 64);        // no search results there: only the block's final records
     pl->maxChunks = (int)((round_up((size_t)maxLen / 4 + 3, 64) + kSeqChunk - 1) / kSeqChunk);
     pl->perBlock = (size_t)pl->chainStride * 2 + (size_t)pl->chainStride * 4 + ((size_t)pl->chainStride + 8) * 4 + (size_t)kHcHashEntries * 4 + (size_t)pl->fStride * 8
                  + sizeof(SeqInfo) + (size_t)pl->maxChunks * 8;
@@ -1161,9 +1215,11 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl, bool lazy)
     if (grp < 1) grp = 1;
     if (grp > nBlocks) grp = nBlocks;
     if (!c->h12ParseWaves) {
-        int per = 0;
+        int per = 0, perSeg = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc12_parse, 64, 0) != hipSuccess || per < 1) per = 8;
-        c->h12ParseWaves = c->cus * per;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perSeg, k_hc12_seg, 64, 0) != hipSuccess || perSeg < 1) perSeg = 8;
+        c->h12SegWaves = c->cus * perSeg;
+        c->h12ParseWaves = c->cus * (per > perSeg ? per : perSeg);           // (sizes the waves' global price-table slots: the larger of the two grids)
     }
     for (;;) {
         {   // groups of equal size: what is allocated is what one of them needs, whatever the budget would allow
@@ -1230,16 +1286,18 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     }
     const bool lazy = use_lazy(a, maxLen);
     if (lazy || use_h12(a, maxLen)) {
+        // level 12 up to 4 MiB: its parser in segments as well (records; larger raw blocks keep the one-wave parser that writes bytes)
+        const bool seg12 = !lazy && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC12_SEG_OFF") == nullptr;
         H12Plan pl;
-        if (int rc = plan_h12(c, nb, maxLen, &pl, lazy)) return rc;
+        if (int rc = plan_h12(c, nb, maxLen, &pl, lazy || seg12, !lazy)) return rc;
         a.h12Chain = (uint16_t*)(c->d_h12 + 256); a.h12ChainStride = pl.chainStride;
         a.h12Rank = (uint32_t*)(c->d_h12 + pl.offRank); a.h12List = (uint32_t*)(c->d_h12 + pl.offList);
         a.h12Offsets = (uint32_t*)(c->d_h12 + pl.offOffsets);
         a.h12F = (Hc12F*)(c->d_h12 + pl.offF); a.h12FStride = pl.fStride;
         a.h12Ws = c->d_h12 + pl.offWs; a.h12Err = (int32_t*)(c->d_h12 + pl.offErr); c->h12ErrOff = pl.offErr;
         a.rawMode = rawMode;
-        if (lazy) {
-            if (a.level >= 10) { if (int rc = ensure_hc(c)) return rc; a.hcWork = c->d_hc; }
+        if (lazy || seg12) {
+            if (lazy && a.level >= 10) { if (int rc = ensure_hc(c)) return rc; a.hcWork = c->d_hc; }
             if (!c->hcLazyWaves) {
                 int per = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc_lazy, 64, 0) != hipSuccess || per < 1) per = 8;
@@ -1269,7 +1327,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);
             if (!lazy) hipLaunchKernelGGL(k_hc12_search, dim3(grid_for(ng, c->cus)), dim3(1024), 0, s, a);
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-            if (!lazy) hipLaunchKernelGGL(k_hc12_parse, dim3(grid_for(ng, c->h12ParseWaves)), dim3(64), 0, s, a);
+            if (!lazy && !seg12) hipLaunchKernelGGL(k_hc12_parse, dim3(grid_for(ng, c->h12ParseWaves)), dim3(64), 0, s, a);
             else {
                 // segments per block: as many as there are 8 KiB pieces, at most 512.  Measured at 4096 blocks of 4 MiB, level 3 /
                 // level 9: 16 segments 7522 / 4870, 32: 7734 / 4986, 64: 7908 / 5090, 128: 8071 / 5691, 256: 8279 / 5958, 512: 8602 /
@@ -1278,10 +1336,16 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
                 a.lzSegs = kLzMaxSegs;
                 if (const char* v = getenv("PLZ4HIP_HC_SEGS")) a.lzSegs = atoi(v);
                 a.lzSegs = a.lzSegs < 1 ? 1 : (a.lzSegs > kLzMaxSegs ? kLzMaxSegs : a.lzSegs);
+                if (seg12) {
+                    hipLaunchKernelGGL(k_hc12_seg, dim3(grid_for(ng * a.lzSegs, c->h12SegWaves)), dim3(64), 0, s, a);
+                    a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+                    hipLaunchKernelGGL(k_hc12_stitch, dim3(grid_for(ng, c->h12SegWaves)), dim3(64), 0, s, a);
+                } else {
                 const int lzWaves = a.level >= 10 && c->hcWaves < c->hcLazyWaves ? c->hcWaves : c->hcLazyWaves;   // (a price table per wave)
                 hipLaunchKernelGGL(k_hc_lazy, dim3(grid_for(ng * a.lzSegs, lzWaves)), dim3(64), 0, s, a);
                 a.queue = next_queue(c, s, &e); HIPCHK(c, e);
                 hipLaunchKernelGGL(k_hc_stitch, dim3(grid_for(ng, lzWaves)), dim3(64), 0, s, a);
+                }
                 hipLaunchKernelGGL(k_hc_gather, dim3(ng >= 1024 ? 4 : 16, ng), dim3(256), 0, s, a);
                 int wg = (16384 / ng) / 4;                                  // emit: waves per block so that a small call still spreads over the chip
                 if (wg > (pl.maxChunks + 3) / 4) wg = (pl.maxChunks + 3) / 4;

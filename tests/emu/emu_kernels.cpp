@@ -162,6 +162,7 @@ int emu_decode_block_dict(const uint8_t* src, int n, uint8_t* dst, int cap, cons
 
 // ---- HC level 12 in its three device phases (lz4hc12_device.inl), back to back on the CPU.
 #include "../../plz4_amd/csrc/lz4hc12_device.inl"
+#include "../../plz4_amd/csrc/lz4hc_lazy_device.inl"
 namespace {
 struct H12Emu {
     uint8_t* padded; uint16_t* chain; uint32_t* rank; uint32_t* listBase; uint32_t* offsets; int n, nPos, nPad;
@@ -220,7 +221,9 @@ struct H12Emu {
 }
 // ncEvery > 0: every ncEvery-th position is left to the parser's own search (the path for positions the search phase skips);
 // nl: entries of the price table kept in "LDS" (small values exercise the global part).
-extern "C" int emu_compress_hc12(const uint8_t* src, int n, uint8_t* dst, int cap, int ncEvery, int nl)
+namespace { int emu_emit_records(const uint8_t* src, int n, const uint64_t* seq, int nseq, int lastAnchor, uint8_t* dst, int cap); }
+// maxSegs > 0: the parser walked in segments and stitched, records through the emit stage (what the kernels run up to 4 MiB)
+extern "C" int emu_compress_hc12(const uint8_t* src, int n, uint8_t* dst, int cap, int ncEvery, int nl, int maxSegs, int minSeg)
 {
     using namespace plz4;
     H12Emu E(src, n);
@@ -236,7 +239,22 @@ extern "C" int emu_compress_hc12(const uint8_t* src, int n, uint8_t* dst, int ca
     w.ent = (Hc12Ent*)aligned_alloc(16, sizeof(Hc12Ent) * (size_t)((nl + 3) & ~3));
     w.gprice = (int*)malloc(4 * kHc12OptEntries); w.glitlen = (int*)malloc(4 * kHc12OptEntries); w.gmloff = (uint32_t*)malloc(4 * kHc12OptEntries);
     uint64_t seq[64]; w.seq = seq;
-    const int r = hc12_parse(E.padded, n, dst, cap, F, E.chain, w);
+    int r;
+    if (maxSegs > 0 && n <= kSeqMaxBlock) {
+        const int segs = lz_segments(n, maxSegs, minSeg), segCap = lz_seg_cap(lz_seg_len(n, segs));
+        uint64_t* rec = (uint64_t*)malloc((size_t)segs * segCap * 8), *bridge = (uint64_t*)malloc((size_t)segs * segCap * 8);
+        uint64_t* starts = (uint64_t*)malloc((size_t)segs * kLzStarts * 8);
+        LzSegMeta* meta = (LzSegMeta*)malloc(sizeof(LzSegMeta) * (size_t)segs);
+        LzPiece* pieces = (LzPiece*)malloc(sizeof(LzPiece) * 2 * (size_t)segs);
+        for (int j = segs - 1; j >= 0; --j) hc12_segment(E.padded, n, F, E.chain, w, segs, j, rec, meta, starts);
+        int lastAnchor = 0;
+        const int nseq = hc12_stitch(E.padded, n, F, E.chain, w, segs, rec, bridge, meta, starts, pieces, &lastAnchor);
+        uint64_t* all = (uint64_t*)malloc(((size_t)n / 4 + 64) * 8);
+        for (int k = 0; k < 2 * segs; ++k) for (int i = 0; i < pieces[k].cnt; ++i) all[pieces[k].dst + i] = pieces[k].src[i];
+        r = emu_emit_records(E.padded, n, all, nseq, lastAnchor, dst, cap);
+        free(all); free(rec); free(bridge); free(starts); free(meta); free(pieces);
+    } else
+    r = hc12_parse(E.padded, n, dst, cap, F, E.chain, w);
     free(w.ent); free(w.gprice); free(w.glitlen); free(w.gmloff);
     free(F);
     return r;

@@ -100,12 +100,12 @@ class Emu:
     def xxh32(self, a: np.ndarray) -> int:
         return int(self.L.emu_xxh32(_ptr(a) if a.size else C.cast(None, u8p), a.size))
 
-    def compress_hc12(self, src, cap, nc_every=0, nl=1024):
+    def compress_hc12(self, src, cap, nc_every=0, nl=1024, max_segs=0, min_seg=8192):
         """Level 12 through the three device phases of lz4hc12_device.inl (chain, per-position search, parser)."""
         self.L.emu_compress_hc12.restype = C.c_int
-        self.L.emu_compress_hc12.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
+        self.L.emu_compress_hc12.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         dst = np.empty(max(cap, 1) + 64, dtype=np.uint8)
-        r = int(self.L.emu_compress_hc12(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, nc_every, nl))
+        r = int(self.L.emu_compress_hc12(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, nc_every, nl, max_segs, min_seg))
         return r, dst[:max(r, 0)]
 
     def hc12_search_check(self, src):

@@ -256,7 +256,8 @@ def test_emu_hc_level2_in_batches(ref, orc, emu):
 # ---- level 12 in its three device phases (plz4_amd/csrc/lz4hc12_device.inl): chains + per-hash lists, F(p) per position, parser
 def test_emu_hc12_vs_reference(ref, orc, emu):
     """The three phases back to back on the CPU == LZ4_compress_HC(level 12), incl. the parser's own search for positions the
-    search phase leaves out (nc) and price-table entries beyond the LDS part (nl)."""
+    search phase leaves out (nc) and price-table entries beyond the LDS part (nl); the one-wave parser that writes bytes (blocks
+    above 4 MiB) and the parser in segments with records (the frame path)."""
     cases = [("T", synth.text(70000)), ("Z", np.zeros(9000, np.uint8)), ("M", synth.make("M", 140000, 65536)[60000:])]
     cases += [(n, c[:6000]) for n, c in corpus.twin_cases()[:2]]
     cases += [c for c in corpus.small_cases() if c[1].size in (0, 5, 12, 13, 14, 40, 300, 4097)]
@@ -267,6 +268,10 @@ def test_emu_hc12_vs_reference(ref, orc, emu):
             for nc, nl in (((0, 1024), (7, 40)) if k < 2 else ((0, 1024),)):
                 b, db = emu.compress_hc12(src, cap, nc, nl)
                 assert a == b and np.array_equal(da, db), (name, src.size, cap, nc, nl, a, b)
+                # ... and with the parser walked in segments and stitched (walks meet on position AND anchor), records + emit
+                for segs, mseg in ((1, 65536), (16, 300)) if k == 0 else ((4, 4096),):
+                    b, db = emu.compress_hc12(src, cap, nc, 256 if nl > 256 else nl, segs, mseg)
+                    assert a == b and np.array_equal(da, db), (name, src.size, cap, nc, nl, segs, mseg, a, b)
 
 
 def test_emu_hc12_search_as_the_kernel_runs_it(emu):
