@@ -26,7 +26,7 @@
  * levels, which run a chunk at a time), level 1 its sequence records (2.25 bytes per input byte of the largest group of blocks
  * in one call, at most half of what is free: PLZ4HIP_L1_BUDGET_GIB) and the HC levels their workspaces between calls;
  * plz4hip_ctx_trim gives them back.  The HC workspaces are sized by the call: on independent blocks levels 3..11 keep 14.5 bytes
- * per input byte of the blocks in flight (chain, per-hash lists, sequence records of the segments), level 12 18, level 2 2.25, out
+ * per input byte of the blocks in flight (chain, per-hash lists, sequence records of the segments), level 12 22.5 (the search results as well), level 2 2.25, out
  * of a quarter of the device memory that is free when the call arrives, at most 64 GiB; a call whose blocks do not fit runs in
  * groups.  A caller that owns the GPU raises the budget with PLZ4HIP_HC_BUDGET_GIB (these kernels live on blocks in flight).
  * Other environment switches, for tests and experiments only: PLZ4HIP_HC_SEGS / PLZ4HIP_HC_MIN_SEG (segments a block is walked

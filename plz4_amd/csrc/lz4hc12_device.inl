@@ -17,9 +17,11 @@
 //       is a function of the data alone as well: F(p) = (length, offset).  It is computed for every position the parser may
 //       ask for, one position per LANE (Hc12Walk), ahead of the parser; the 64 KiB of source behind the positions in flight
 //       sit in LDS, so the 2-byte / 4-byte tests of a candidate (95 % of all candidates end there) never leave the CU.
-//   The price DP stays serial per block but touches no match finder any more (hc12_parse): it reads F, scans the skip test
-//   (:1929-1934) for 64 positions at once, updates the prices of a match's lengths one length per lane, and hands the chosen
-//   sequences to a writer that lays out 64 sequences at a time.
+//   The price DP touches no match finder any more (hc12_walk): it reads F, scans the skip test (:1929-1934) for 64 positions at
+//   once and updates the prices of a match's lengths one length per lane.  Up to 4 MiB a block is walked in segments at once
+//   (lz4hc_lazy_device.inl: at the top of its loop the parser's state is (ip, anchor), so a wave may start there anywhere and
+//   the walks are stitched where they meet), its sequences are records and level 1's emit stage writes them; larger raw blocks
+//   keep one wave per block that hands the sequences to a writer of its own, 64 at a time.
 //
 // Everything here is also compiled by g++ for tests/emu (PLZ4_EMU), where the three phases run back to back on the CPU and are
 // checked against the real LZ4_compress_HC of oracle/_ref.
