@@ -332,6 +332,8 @@ def main():
             eng.dev_encode_records(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["stage"].data_ptr(), pt["len"].data_ptr(), s_enc.cuda_stream,
                                    level=args.level)
             if e: e[1].record(s_enc)
+            if s_gat is not None:
+                s_enc.wait_stream(s_gat)                       # the previous step's sends (and interleave) still read this body
             eng.dev_compact_records(pt["stage"].data_ptr(), stride, pt["len"].data_ptr(), pt["nb"], pt["off"].data_ptr(),
                                     pt["body"].data_ptr(), pt["body"].numel(), s_enc.cuda_stream)
             packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
@@ -351,8 +353,9 @@ def main():
             if e: e[5].record(s_dec)
         if s_dec is not s_enc:
             done = torch.cuda.Event(); done.record(s_dec); s_enc.wait_event(done)
-        if s_gat is not None:
-            s_enc.wait_stream(s_gat)                           # the step ends when the frame is assembled, too
+        # N > 1: the exchange of this step's records runs on under the next step's encode (it is done long before that encode
+        # reaches its compact, which waits for it above); the barrier + synchronize that close the timed region wait for the last
+        # one, so K steps are K encodes, K decodes and K assembled frames
 
     # ---- correctness gate before any timing: round trip bit-exact, every block status OK (records vs the reference: cpu_baseline leg)
     d_out.zero_()

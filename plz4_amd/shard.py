@@ -67,7 +67,10 @@ def gather_frame_body(body: torch.Tensor, rec_len: torch.Tensor, rank: int, worl
     if rank != 0:
         c = cuts[rank]
         for t in range(len(c) - 1):
-            dist.send(body[offs[rank][c[t]]:offs[rank][c[t + 1]]], dst=0)
+            # the same group form as the receiver's: torch runs grouped and single send / recv on different communicators
+            # (device-keyed vs pair-keyed), so both ends of a transfer have to take the same one
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, body[offs[rank][c[t]]:offs[rank][c[t + 1]]], 0)]):
+                q.wait()
         return None, totals[rank]
     need = max([offs[r][cuts[r][t + 1]] - offs[r][cuts[r][t]] for r in range(1, world) for t in range(len(cuts[r]) - 1)] + [1])
     if scratch.get("cap", 0) < need or scratch.get("world") != world:
@@ -83,13 +86,15 @@ def gather_frame_body(body: torch.Tensor, rec_len: torch.Tensor, rank: int, worl
         return scratch["recv"][base:base + cap]
 
     def post(t):
-        reqs = []
+        # one group call for the round (ncclGroupStart / End under RCCL): the pieces of all senders arrive at once, each over
+        # its own xGMI link, instead of one receive after the other on the communicator's stream
+        ops = []
         for r in range(1, world):
             c = cuts[r]
             if t < len(c) - 1:
                 nbytes = offs[r][c[t + 1]] - offs[r][c[t]]
-                reqs.append(dist.irecv(slot(r, t)[:nbytes], src=r))
-        return reqs
+                ops.append(dist.P2POp(dist.irecv, slot(r, t)[:nbytes], r))
+        return dist.batch_isend_irecv(ops) if ops else []
 
     dst_off, total = interleave_offsets(lens)
     reqs = post(0) if rounds else []
