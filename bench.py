@@ -6,10 +6,14 @@ the dominant kernel and plz4's CPU path timed beside it.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--blocks B] [--kind T|R|Z|M]
     N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL), see the contract in the task statement.
 
-One step = one pass of the hot path over one batch that is already resident in HBM:
-    encode kernel (B blocks -> staged records, fused xxh32) -> scan + compaction into the frame body
-    [N > 1: RCCL gather of the bodies to rank 0 + interleave into the final frame body]
-    -> decode kernel (frame body -> B plaintext blocks, checksum verified).
+One step = one pass of the hot path, both directions, over one batch that is already resident in HBM:
+    ONE duplex call (plz4hip_dev_duplex_records): the level-1 encode of this step's B blocks (-> staged records + xxh32)
+    and, in the same launch, the decode of the frame body the previous step produced (-> B plaintext blocks, checksums
+    verified) -- a writer's next batch beside a reader's;  -> scan + compaction of the new records into the frame body
+    [N > 1: RCCL gather of the bodies to rank 0 + interleave into the final frame body].
+Every step is one full encode and one full decode of B blocks; the body the last step produced is decoded and compared
+after the timed region.  `--duplex 0` (and every HC level) runs the step as encode -> frame body -> decode of the same
+batch, one call after the other; at N = 1 the default run times those K steps as well and reports them as `serial_step`.
 Blocks are independent, so ranks share nothing on the data path (weak scaling: B blocks per GPU); block i of the
 global stream lives on rank i mod N.
 """
@@ -214,6 +218,10 @@ def main():
     ap.add_argument("--pipe", type=int, default=int(os.environ.get("PLZ4_BENCH_PIPE", "1")),
                     help="parts per step; decode of part p overlaps encode of part p+1 on a second stream (1 = serial)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--duplex", type=int, default=int(os.environ.get("PLZ4_BENCH_DUPLEX", "1")),
+                    help="level 1 only.  1 (default): a step is ONE duplex call (plz4hip_dev_duplex_records): the level-1 encode of this step's batch beside the "
+                         "decode of the frame body the previous step produced (the decoder's waves share every CU with the parser's), "
+                         "then scan + compact; 0: encode -> frame body -> decode of the same batch, one after the other")
     ap.add_argument("--decode-only", action="store_true",
                     help="configs[2]: the step is the decode of the (already framed, resident) records alone; blocks stay sharded "
                          "block i -> rank i mod N, the plaintext stays on the rank that decoded it")
@@ -290,6 +298,13 @@ def main():
             "res": torch.zeros(nb, dtype=torch.int32, device=dev),
             "st": torch.zeros(nb, dtype=torch.int32, device=dev),
         })
+    duplex = bool(args.duplex) and args.level == 1 and NP == 1 and not args.decode_only
+    if duplex:
+        # two frame bodies: the decode side of a duplex call reads the one the previous step compacted while this step's goes to the other
+        pt = parts[0]
+        pt["bodies"] = [pt["body"], torch.empty_like(pt["body"])]
+        pt["offs"] = [pt["off"], torch.zeros_like(pt["off"])]
+        pt["cur"] = 0
     s_enc = torch.cuda.current_stream()
     s_dec = torch.cuda.Stream(device=dev) if NP > 1 else s_enc
     # N > 1: the framed-output gather (RCCL send/recv + the interleave on rank 0) runs on its own stream, next to the decode
@@ -321,10 +336,39 @@ def main():
                                    pt["res"].data_ptr(), pt["st"].data_ptr(), s_enc.cuda_stream)
             if e: e[5].record(s_enc)
 
-    def step(ev=None):
+    def step_duplex(ev=None):
+        """one duplex call: encode of this step's batch + decode of the previous step's frame body; then scan + compact"""
+        gather["live"] = []
+        pt = parts[0]
+        e = ev[0] if ev else None
+        prv = pt["cur"]; cur = 1 - prv
+        if e: e[0].record(s_enc)
+        eng.dev_duplex_records(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["stage"].data_ptr(), pt["len"].data_ptr(),
+                               pt["bodies"][prv].data_ptr(), pt["offs"][prv].data_ptr(), pt["nb"], BSZ, True,
+                               pt["out"].data_ptr(), BSZ, BSZ, pt["res"].data_ptr(), pt["st"].data_ptr(), s_enc.cuda_stream)
+        if e: e[1].record(s_enc)
+        if s_gat is not None:
+            s_enc.wait_stream(s_gat)
+        eng.dev_compact_records(pt["stage"].data_ptr(), stride, pt["len"].data_ptr(), pt["nb"], pt["offs"][cur].data_ptr(),
+                                pt["bodies"][cur].data_ptr(), pt["bodies"][cur].numel(), s_enc.cuda_stream)
+        pt["cur"] = cur; pt["body"] = pt["bodies"][cur]; pt["off"] = pt["offs"][cur]
+        packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
+        packed.record(s_enc)
+        if multi:
+            s_gat.wait_event(packed)
+            with torch.cuda.stream(s_gat):
+                frame_gather(pt)
+                if e: e[3].record(s_gat)
+        elif e:
+            e[3].record(s_enc)
+        if e: e[4].record(s_enc); e[5].record(s_enc)
+
+    def step(ev=None, serial=False):
         """ev: per part [enc0, enc1, cmp1, gat1, dec0, dec1] events."""
         if ev is not None and args.decode_only:
             return step_decode(ev)
+        if ev is not None and duplex and not serial:
+            return step_duplex(ev)
         gather["live"] = []
         for i, pt in enumerate(parts):
             e = ev[i] if ev else None
@@ -374,8 +418,10 @@ def main():
         log("parity gate ok: round trip exact, every block status OK, stored/plain ratio %.4f "
             "(two records are compared with the reference encoder in the cpu_baseline leg)" % (C_bytes / S))
 
+    if duplex:
+        d_out.zero_()                                                        # what the timed steps decode is checked again below
     for _ in range(args.warmup):
-        step_decode() if args.decode_only else step()
+        step_decode() if args.decode_only else (step_duplex() if duplex else step())
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -389,6 +435,31 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if duplex:
+        # every timed step decoded the body of the step before it (the first one the warm-up's or the gate's): the plaintext must
+        # be back, and so must the plaintext of the last body, decoded here outside the timed region
+        pt = parts[0]
+        if args.steps + args.warmup > 0:
+            assert int(pt["st"].abs().sum().item()) == 0 and torch.equal(d_out, d_src), "duplex: round trip mismatch"
+        d_out.zero_()
+        eng.dev_decode_records(pt["body"].data_ptr(), pt["off"].data_ptr(), pt["nb"], BSZ, True, pt["out"].data_ptr(), BSZ, BSZ,
+                               pt["res"].data_ptr(), pt["st"].data_ptr(), s_enc.cuda_stream)
+        torch.cuda.synchronize()
+        assert int(pt["st"].abs().sum().item()) == 0 and torch.equal(d_out, d_src), "duplex: last body does not decode to the input"
+    serial_leg = None
+    if duplex and not multi:
+        # beside the headline: the same K steps as encode -> frame body -> decode of the same batch, one call after the other (the
+        # step of rounds 1-2), which is also where the encode call and k_decode_rec are timed by themselves
+        evs2 = [[[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in parts] for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(evs2[k], serial=True)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        seg2 = np.array([[sum(e[0].elapsed_time(e[1]) for e in st_), sum(e[1].elapsed_time(e[2]) for e in st_),
+                          sum(e[2].elapsed_time(e[3]) for e in st_), sum(e[4].elapsed_time(e[5]) for e in st_)] for st_ in evs2])
+        serial_leg = (el2, seg2.mean(axis=0).tolist())
     # ms per step, summed over the parts: encode kernel, scan+compact, gather, decode kernel (decode overlaps the next encode)
     seg = np.array([[sum(e[0].elapsed_time(e[1]) for e in st_), sum(e[1].elapsed_time(e[2]) for e in st_),
                      sum(e[2].elapsed_time(e[3]) for e in st_), sum(e[4].elapsed_time(e[5]) for e in st_)] for st_ in evs])
@@ -407,6 +478,7 @@ def main():
                       ("k_hc12_hist+k_hc12_chain+k_hc_lazy+k_hc_stitch+k_hc_gather+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if 3 <= args.level <= 11 else
                        ("k_hc_mid+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if args.level == 2 else "k_encode_rec_hc")))
         ach_enc = (S + C_bytes) / (enc_ms * 1e-3) / 1e9
+        dec_ms = max(dec_ms, 1e-6)                                              # (duplex: no decode launch of its own)
         ach_dec = (S + C_bytes) / (dec_ms * 1e-3) / 1e9
         if args.decode_only:
             line = {
@@ -455,8 +527,40 @@ def main():
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_dec / HBM_PEAK_GBS, 5),
                                 "traffic": None},
         }
+        if duplex:
+            # one call does both directions: its algorithmic bytes are the encode's (S read + C written) plus the decode's (C read + S
+            # written), over the call's time (k_l1_duplex + the four emit kernels)
+            enc_kernel = "k_l1_duplex+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish"
+            ach = 2 * (S + C_bytes) / (enc_ms * 1e-3) / 1e9
+            out["config"]["workload"] = out["config"]["workload"].replace(
+                "step = encode->frame body->decode",
+                "step = ONE duplex call (encode of this step's batch beside the decode of the frame body the previous step produced; every "
+                "step is one full encode and one full decode, the last body is decoded and checked after the timed region) -> frame body")
+            out["config"]["duplex"] = True
+            out["roofline"] = {"bound": "hbm", "kernel": enc_kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None}
+            out["ms"] = {"duplex_call": round(enc_ms, 3), "scan_compact": round(cmp_ms, 3), "frame_gather": round(gat_ms, 3)}
+            del out["roofline_decode"], out["enc_MiBps_per_gpu"], out["dec_MiBps_per_gpu"]
+            if serial_leg:
+                el2, (e2, c2, g2, d2) = serial_leg
+                ms2 = el2 / args.steps * 1e3
+                a_e = (S + C_bytes) / (e2 * 1e-3) / 1e9; a_d = (S + C_bytes) / (d2 * 1e-3) / 1e9
+                k_e = "k_l1_parse+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish"
+                out["serial_step"] = {
+                    "what": "the same %d steps as encode -> frame body -> decode of the same batch, one call after the other" % args.steps,
+                    "value": round(world * mib / (ms2 * 1e-3), 1), "unit": "MiB/s", "ms_per_step": round(ms2, 3),
+                    "enc_MiBps_per_gpu": round(mib / (e2 * 1e-3), 1), "dec_MiBps_per_gpu": round(mib / (d2 * 1e-3), 1),
+                    "ms": {"encode_kernel": round(e2, 3), "scan_compact": round(c2, 3), "decode_kernel": round(d2, 3)},
+                    "roofline": {"bound": "hbm", "kernel": k_e, "achieved": round(a_e, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(a_e / HBM_PEAK_GBS, 5), "traffic": None},
+                    "roofline_decode": {"bound": "hbm", "kernel": "k_decode_rec", "achieved": round(a_d, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(a_d / HBM_PEAK_GBS, 5), "traffic": None}}
+                for key, kern in (("roofline", k_e), ("roofline_decode", "k_decode_rec")):
+                    t = committed_traffic(kern, B)
+                    if t:
+                        out["serial_step"][key]["traffic"] = t["bytes"]; out["serial_step"][key]["traffic_source"] = t["source"]
         for key, kern in (("roofline", enc_kernel), ("roofline_decode", "k_decode_rec")):
-            t = committed_traffic(kern, B)
+            t = committed_traffic(kern, B) if key in out else None
             if t:
                 out[key]["traffic"] = t["bytes"]; out[key]["traffic_source"] = t["source"]
         if world == 1 and not args.no_cpu_baseline:

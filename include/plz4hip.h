@@ -215,6 +215,17 @@ int plz4hip_dev_decode_records(plz4hip_ctx* ctx, const void* body, const int64_t
                                int bsz, int blockChecksum, void* dst, int64_t dstStride, int dstCap,
                                int32_t* result, int32_t* status, void* stream);
 
+/* plz4hip_dev_duplex_records: plz4hip_dev_encode_records (level 1) of one batch AND plz4hip_dev_decode_records of another --
+ * a writer's next batch and a reader's -- enqueued as one call, with results identical to the two calls made one after the
+ * other; the operands of the two sides must not overlap.  The reference runs its compress and decompress workers side by side
+ * on the host's cores (async/writer.go:232-282, async/reader.go:192-221); here the decoder's waves share every CU with the
+ * level-1 parser's (k_l1_duplex): the parser is a serial chain per block that leaves about half of the vector issue slots
+ * idle, the decoder is bound by those slots, so the decode costs the pair little more than the parse alone.  Either side may be
+ * empty (srcBytes == 0 / nDecBlocks == 0). */
+int plz4hip_dev_duplex_records(plz4hip_ctx* ctx, const void* src, int64_t srcBytes, int bsz, int blockChecksum, void* stage, int32_t* recLen,
+                               const void* body, const int64_t* recOff, int nDecBlocks, int decBsz, int decBlockChecksum,
+                               void* dst, int64_t dstStride, int dstCap, int32_t* result, int32_t* status, void* stream);
+
 /* Raw LZ4 blocks on the device (no record framing): block i = src + i*srcStride (srcLen[i] bytes) ->
  * dst + i*dstStride (capacity dstCap[i]); result[i] as in A, levels 1..12.  srcLen/dstCap/result are device arrays; maxLen
  * (host value, >= every srcLen[i]) sizes the HC workspace and is only read for levels 2..12.

@@ -18,7 +18,7 @@ SYMBOLS = [
     "plz4hip_last_error", "plz4hip_compress_bound", "plz4hip_compress_batch", "plz4hip_decompress_batch",
     "plz4hip_xxh32_batch", "plz4hip_encode_records", "plz4hip_decode_records", "plz4hip_dev_stage_stride",
     "plz4hip_dev_encode_records", "plz4hip_dev_compact_records", "plz4hip_dev_scatter_records",
-    "plz4hip_dev_decode_records", "plz4hip_dev_compress", "plz4hip_dev_decompress", "plz4hip_ctx_trim",
+    "plz4hip_dev_decode_records", "plz4hip_dev_duplex_records", "plz4hip_dev_compress", "plz4hip_dev_decompress", "plz4hip_ctx_trim",
     "plz4hip_dev_resident_waves", "plz4hip_dict_create", "plz4hip_dict_destroy", "plz4hip_compress_batch_dict", "plz4hip_decode_records_chains",
     "plz4hip_decompress_batch_dict", "plz4hip_encode_records_ex", "plz4hip_decode_records_ex",
     "plz4hip_xxh32_stream_create", "plz4hip_xxh32_stream_destroy", "plz4hip_xxh32_stream_reset", "plz4hip_xxh32_stream_update",
@@ -88,6 +88,9 @@ def load():
     L.plz4hip_dev_scatter_records.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, C.c_int64, vp]
     L.plz4hip_dev_decode_records.restype = C.c_int
     L.plz4hip_dev_decode_records.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp, vp, vp]
+    L.plz4hip_dev_duplex_records.restype = C.c_int
+    L.plz4hip_dev_duplex_records.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp,
+                                             vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp, vp, vp]
     L.plz4hip_dev_compress.restype = C.c_int
     L.plz4hip_dev_compress.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp]
     L.plz4hip_dev_decompress.restype = C.c_int
@@ -327,6 +330,14 @@ class Engine:
     def dev_decode_records(self, body_ptr, recoff_ptr, nblocks, bsz, block_checksum, dst_ptr, dst_stride, dst_cap,
                            result_ptr, status_ptr, stream=0):
         self._chk(self.L.plz4hip_dev_decode_records(self.h, body_ptr, recoff_ptr, nblocks, bsz, int(block_checksum), dst_ptr,
+                                                    dst_stride, dst_cap, result_ptr, status_ptr, stream))
+
+    def dev_duplex_records(self, src_ptr, src_bytes, bsz, block_checksum, stage_ptr, reclen_ptr,
+                           body_ptr, recoff_ptr, ndec, dec_bsz, dec_block_checksum, dst_ptr, dst_stride, dst_cap,
+                           result_ptr, status_ptr, stream=0):
+        """level-1 encode of one batch and record decode of another in one call (k_l1_duplex)"""
+        self._chk(self.L.plz4hip_dev_duplex_records(self.h, src_ptr, src_bytes, bsz, int(block_checksum), stage_ptr, reclen_ptr,
+                                                    body_ptr, recoff_ptr, ndec, dec_bsz, int(dec_block_checksum), dst_ptr,
                                                     dst_stride, dst_cap, result_ptr, status_ptr, stream))
 
     def stage_stride(self, bsz: int) -> int:

@@ -143,9 +143,8 @@ template <int W> __global__ __launch_bounds__(64 * W) void k_encode_rec(CodecArg
 // ---- level 1 in stages (independent blocks up to 4 MiB, no dictionary): lz4_seq_device.inl ------------------------------------
 // k_l1_parse: persistent, one wave per block, the hash table in LDS -- the only serial stage; it writes one 8-byte record per
 // sequence.  The others are plain data-parallel kernels, one lane per sequence, any number of waves per block, no LDS.
-template <int W> __global__ __launch_bounds__(64 * W) void k_l1_parse(CodecArgs a)
+__device__ __forceinline__ void l1_parse_loop(const CodecArgs& a, uint32_t* lds)
 {
-    ENC_WAVE_TABLE(lds);
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
         const int gi = a.blk0 + i;
         const int n  = block_len(a, gi);
@@ -154,6 +153,11 @@ template <int W> __global__ __launch_bounds__(64 * W) void k_l1_parse(CodecArgs 
             nseq = wave_parse_l1(a.src + (int64_t)gi * a.srcStride, n, lds, a.l1Seq + (int64_t)i * a.l1SeqStride, &lastAnchor);
         if ((threadIdx.x & 63u) == 0) { SeqInfo inf; inf.nseq = nseq; inf.lastAnchor = lastAnchor; inf.total = 0; inf.stored = 0; a.l1Info[i] = inf; }
     }
+}
+template <int W> __global__ __launch_bounds__(64 * W) void k_l1_parse(CodecArgs a)
+{
+    ENC_WAVE_TABLE(lds);
+    l1_parse_loop(a, lds);
 }
 
 // grid (waves per block / 4, blocks of the group): bytes of every chunk of 1024 sequences.  kBack: the level-1 parser's records
@@ -892,9 +896,8 @@ __global__ __launch_bounds__(64) void k_decode_raw(CodecArgs a)
 
 // FrameReader._read's per-block checks + BlkT.Decompress on the device (blk/frame.go:54-127, blk.go:50-61).
 // Record i starts at src + recOff[i] when recOff is given, else at src + i*srcStride with srcLen[i] bytes.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_decode_rec(CodecArgs a)
+__device__ __forceinline__ void decode_rec_loop(const CodecArgs& a, uint8_t* dl)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t dl[kDecLdsBytes];       // the vector path assembles each batch's output here
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
         const uint8_t* rec    = a.recOff ? a.src + a.recOff[i] : a.src + (int64_t)i * a.srcStride;
         const int64_t  recLen = a.recOff ? a.recOff[i + 1] - a.recOff[i] : (int64_t)a.srcLen[i];
@@ -921,6 +924,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
             }
         }
         if ((threadIdx.x & 63u) == 0) { a.result[i] = r; a.status[i] = st; }
+    }
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_decode_rec(CodecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t dl[kDecLdsBytes];       // the vector path assembles each batch's output here
+    decode_rec_loop(a, dl);
+}
+
+// The level-1 parse of one call and the record decode of another in ONE launch (plz4hip_dev_duplex_records).  The parser is a
+// serial chain per block that leaves half of a SIMD's VALU issue slots idle at the 2.5 waves per SIMD its LDS tables allow
+// (profiles/r03_summary.json: 51 %), and the decoder is bound by exactly those slots (85-92 %) and needs 1.1 KiB of LDS per
+// wave.  Two kernels on two streams do not share a CU that way: the parser's workgroup takes all of a CU's LDS.  So a
+// workgroup here is P parser waves (a 16 KiB table each) + D decoder waves -- by default 1 + 1, nine workgroups per CU: 9
+// parsers and 9 decoders -- and the parser waves run at a raised priority: the decoders issue when a parser waits.
+// Each role pulls block ids from its own queue until it is empty; the waves of a workgroup never synchronise.
+// (P parser waves + D decoder waves per workgroup: experiment switch PLZ4HIP_DUPLEX="P,D"; PRIO: the parser waves' s_setprio,
+// PLZ4HIP_DUPLEX_PRIO)
+constexpr int duplex_wgs_per_cu(int P, int D) { return (160 * 1024) / (P * kHashBytes + D * kDecLdsBytes); }
+constexpr int duplex_waves_per_eu(int P, int D) { return ((P + D) * duplex_wgs_per_cu(P, D) + 3) / 4; }
+template <int P, int D, int PRIO> __global__ __launch_bounds__(64 * (P + D))
+__attribute__((amdgpu_waves_per_eu(duplex_waves_per_eu(P, D), duplex_waves_per_eu(P, D))))
+void k_l1_duplex(CodecArgs a, CodecArgs d)
+{
+    __shared__ uint32_t tabS[P][kHashBytes / 4];
+    __shared__ __attribute__((aligned(16))) uint8_t dlS[D][kDecLdsBytes];
+    const int w = plz4_readfirstlane((int)(threadIdx.x >> 6));
+    if (w < P) {
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+        l1_parse_loop(a, tabS[w]);
+    } else {
+        decode_rec_loop(d, dlS[w - P]);
     }
 }
 
@@ -1269,7 +1303,8 @@ bool use_h12(const CodecArgs& a, int maxLen) { return a.level >= 12 && !a.hcEx &
 // levels 3..11, independent blocks up to 4 MiB: segments walked at once, stitched, record emit (lz4hc_lazy_device.inl)
 bool use_lazy(const CodecArgs& a, int maxLen) { return a.level >= 3 && a.level <= 11 && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_LAZY_OFF") == nullptr; }
 
-int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws, bool* midDeclined = nullptr);
+int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws, bool* midDeclined = nullptr,
+              const CodecArgs* rider = nullptr);
 
 // Enqueue one HC call of nb blocks (a: everything but queue / workspace filled in) on s.  rawMode: LZ4 blocks, else records.
 int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode)
@@ -1461,7 +1496,10 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
 // Larger blocks (raw block API only) and calls that do not say how long their blocks are keep the fused kernels.
 // midDeclined: the call is a level-2 call (k_hc_mid instead of k_l1_parse, records without catch-up); set when no workspace could
 // be had, the caller then runs its one-kernel path.
-int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws, bool* midDeclined)
+// rider: the record decode of another call (queue filled in) that shares the parse kernel's launch (k_l1_duplex); a call that
+// runs in groups carries it in its first group, one that takes the fused kernels launches it by itself.
+int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws, bool* midDeclined,
+              const CodecArgs* rider)
 {
     hipError_t e;
     const bool mid = midDeclined != nullptr;
@@ -1504,6 +1542,7 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     if (fused) {
         a.queue = next_queue(c, s, &e); HIPCHK(c, e);
         if (rawMode) ENC_LAUNCH(k_encode_raw, nb, c, s, a); else ENC_LAUNCH(k_encode_rec, nb, c, s, a);
+        if (rider) hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(rider->nBlocks, c->decWaves)), dim3(64), 0, s, *rider);
         HIPCHK(c, hipGetLastError());
         return PLZ4HIP_OK;
     }
@@ -1519,6 +1558,25 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         a.blk0 = g0; a.nBlocks = ng;
         a.queue = next_queue(c, s, &e); HIPCHK(c, e);
         if (mid) hipLaunchKernelGGL(k_hc_mid, dim3(grid_for(ng, c->hcWaves)), dim3(64), 0, s, a);
+        else if (rider && g0 == 0) {
+            // workgroups: what the device holds at once, unless neither role has that much to do
+            int P = 1, D = 1, prio = 3;
+            if (const char* ev = getenv("PLZ4HIP_DUPLEX")) { if (sscanf(ev, "%d,%d", &P, &D) != 2) { P = 1; D = 1; } }
+            if (const char* ev = getenv("PLZ4HIP_DUPLEX_PRIO")) prio = atoi(ev);
+#define DUPLEX_CASE(PP, DD) \
+            if (P == PP && D == DD) { \
+                int wgs = ((ng + PP - 1) / PP > (rider->nBlocks + DD - 1) / DD) ? (ng + PP - 1) / PP : (rider->nBlocks + DD - 1) / DD; \
+                const int hold = c->cus * duplex_wgs_per_cu(PP, DD); \
+                if (wgs > hold) wgs = hold; \
+                if (prio) hipLaunchKernelGGL((k_l1_duplex<PP, DD, 3>), dim3(wgs), dim3(64 * (PP + DD)), 0, s, a, *rider); \
+                else      hipLaunchKernelGGL((k_l1_duplex<PP, DD, 0>), dim3(wgs), dim3(64 * (PP + DD)), 0, s, a, *rider); \
+                launched = true; \
+            }
+            bool launched = false;
+            DUPLEX_CASE(1, 1) DUPLEX_CASE(1, 2) DUPLEX_CASE(3, 4) DUPLEX_CASE(9, 7)      // (9+5, 9+3, 3+2 measured as well: DESIGN 3.1b)
+#undef DUPLEX_CASE
+            if (!launched) return fail(c, PLZ4HIP_E_ARG, "PLZ4HIP_DUPLEX: not a built combination");
+        }
         else ENC_LAUNCH(k_l1_parse, ng, c, s, a);
         // emit: waves per block so that a small call still spreads over the chip
         int wg = (16384 / ng) / 4;
@@ -1792,6 +1850,38 @@ int plz4hip_dev_decode_records(plz4hip_ctx* c, const void* body, const int64_t* 
     hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
     HIPCHK(c, hipGetLastError());
     return PLZ4HIP_OK;
+}
+
+int plz4hip_dev_duplex_records(plz4hip_ctx* c, const void* src, int64_t srcBytes, int bsz, int blockChecksum, void* stage, int32_t* recLen,
+                               const void* body, const int64_t* recOff, int nDecBlocks, int decBsz, int decBlockChecksum,
+                               void* dst, int64_t dstStride, int dstCap, int32_t* result, int32_t* status, void* stream)
+{
+    if (!c || srcBytes < 0 || bsz <= 0 || !stage || !recLen) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_duplex_records: bad argument (encode side)");
+    if (nDecBlocks < 0 || !body || !recOff || !dst || !result || !status || decBsz <= 0) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_duplex_records: bad argument (decode side)");
+    const int64_t nb64 = (srcBytes + bsz - 1) / bsz;
+    if (nb64 > 0x7FFFFFFF) return fail(c, PLZ4HIP_E_ARG, "too many blocks");
+    const int nBlocks = (int)nb64;
+    if (nBlocks == 0 && nDecBlocks == 0) return PLZ4HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    ENTER_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    CodecArgs d{};
+    d.src = (const uint8_t*)body; d.recOff = recOff; d.bsz = decBsz;
+    d.dst = (uint8_t*)dst; d.dstStride = dstStride; d.dstCapAll = dstCap;
+    d.result = result; d.status = status; d.nBlocks = nDecBlocks; d.blockChecksum = decBlockChecksum;
+    d.dictLen = -1; d.prevTailLen = -1;
+    if (nDecBlocks > 0) { hipError_t e; d.queue = next_queue(c, s, &e); HIPCHK(c, e); }
+    if (nBlocks == 0) {
+        hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nDecBlocks, c->decWaves)), dim3(64), 0, s, d);
+        HIPCHK(c, hipGetLastError());
+        return PLZ4HIP_OK;
+    }
+    CodecArgs a{};
+    a.src = (const uint8_t*)src; a.srcStride = bsz; a.srcBytes = srcBytes; a.bsz = bsz;
+    a.dst = (uint8_t*)stage; a.dstStride = plz4hip_dev_stage_stride(bsz);
+    a.result = recLen; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
+    a.dictLen = -1; a.prevTailLen = -1;
+    return launch_l1(c, s, a, nBlocks, bsz, 0, nullptr, nullptr, nDecBlocks > 0 ? &d : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------- host-buffer API

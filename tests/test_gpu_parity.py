@@ -297,6 +297,74 @@ def test_gpu_host_calls_in_many_chunks(orc, monkeypatch):
     e.close()
 
 
+@pytest.mark.parametrize("budget_mib", [0, 40])
+def test_gpu_duplex_call(orc, monkeypatch, budget_mib):
+    """plz4hip_dev_duplex_records == plz4hip_dev_encode_records of one batch + plz4hip_dev_decode_records of another (k_l1_duplex:
+    one parser wave and two decoder waves per workgroup): the records are the oracle's, the decoded blocks the other batch's
+    plaintext with every status OK -- a damaged record reports as it does in the plain call -- also when the encode side runs in
+    groups (the decode rides in the first one) and when either side is empty."""
+    import torch
+    from plz4_amd._native import Engine
+    if budget_mib:
+        monkeypatch.setenv("PLZ4HIP_L1_BUDGET_MIB", str(budget_mib))
+    e = Engine(0)
+    bsz = 4 << 20
+    dataA = synth.make("M", 6 * bsz + 4321, bsz)
+    dataB = synth.make("T", 9 * bsz + 77, bsz)
+    nA = (dataA.size + bsz - 1) // bsz; nB = (dataB.size + bsz - 1) // bsz
+    wantA = orc.frame_encode(dataA, 7, block_checksum=True, content_checksum=False)[7:-4]
+    recsB = [orc.block_record(dataB[o:o + bsz], bsz, True) for o in range(0, dataB.size, bsz)]
+    recsB[4] = recsB[4].copy(); recsB[4][100] ^= 0x40                       # block 4: its checksum no longer matches
+    offB = np.zeros(nB + 1, dtype=np.int64); offB[1:] = np.cumsum([r.size for r in recsB])
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(dataA).to(dev)
+    stride = e.stage_stride(bsz)
+    d_stage = torch.zeros(nA * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(nA, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(nA + 1, dtype=torch.int64, device=dev)
+    d_bodyA = torch.empty(dataA.size + 8 * nA, dtype=torch.uint8, device=dev)
+    d_bodyB = torch.from_numpy(np.concatenate(recsB)).to(dev)
+    d_offB = torch.from_numpy(offB).to(dev)
+    d_out = torch.zeros(nB * bsz, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(nB, dtype=torch.int32, device=dev)
+    d_st = torch.full((nB,), -9, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def check_encode():
+        e.dev_compact_records(d_stage.data_ptr(), stride, d_len.data_ptr(), nA, d_off.data_ptr(), d_bodyA.data_ptr(), d_bodyA.numel(), s)
+        torch.cuda.synchronize()
+        total = int(d_off[-1].item())
+        assert total == wantA.size and np.array_equal(d_bodyA[:total].cpu().numpy(), wantA)
+
+    def check_decode():
+        st = d_st.cpu().numpy(); res = d_res.cpu().numpy(); out = d_out.cpu().numpy()
+        for i in range(nB):
+            blk = dataB[i * bsz:(i + 1) * bsz]
+            if i == 4:
+                assert st[i] != 0                                            # (PLZ4HIP_BLK_HASH_MISMATCH)
+            else:
+                assert st[i] == 0 and res[i] == blk.size and np.array_equal(out[i * bsz:i * bsz + blk.size], blk), i
+
+    e.dev_duplex_records(d_src.data_ptr(), dataA.size, bsz, True, d_stage.data_ptr(), d_len.data_ptr(),
+                         d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+    check_encode(); check_decode()
+    want_st = d_st.clone()
+    e.dev_decode_records(d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(want_st, d_st)                                        # the same status codes as the plain call
+    # either side empty
+    d_stage.zero_(); d_len.zero_(); d_out.zero_(); d_st.fill_(-9)
+    e.dev_duplex_records(d_src.data_ptr(), dataA.size, bsz, True, d_stage.data_ptr(), d_len.data_ptr(),
+                         d_bodyB.data_ptr(), d_offB.data_ptr(), 0, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+    check_encode()
+    assert int((d_st != -9).sum().item()) == 0
+    e.dev_duplex_records(d_src.data_ptr(), 0, bsz, True, d_stage.data_ptr(), d_len.data_ptr(),
+                         d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+    torch.cuda.synchronize()
+    check_decode()
+    e.close()
+
+
 def test_gpu_level1_in_groups(orc, monkeypatch):
     """The staged level-1 call keeps 9 bytes of workspace per possible sequence of the blocks of one group; a call that does not
     fit the memory set aside runs in groups of equal size.  A 40 MiB budget makes 4 MiB blocks go four to a group: records and raw
@@ -393,3 +461,9 @@ def test_gpu_bench_modes_run_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert "configs[2]" in line["config"]["workload"] and line["value"] > 0 and line["roofline"]["kernel"] == "k_decode_rec"
+    for dup in ("1", "0"):                                                   # the duplex step and the serial one, gather path included
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--blocks", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                              "--duplex", dup], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["value"] > 0 and ("k_l1_duplex" in line["roofline"]["kernel"]) == (dup == "1")
