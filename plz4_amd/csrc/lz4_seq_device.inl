@@ -639,7 +639,9 @@ DEV int seq_backext_from(const uint8_t* __restrict__ src, int pos, int cnd, int 
 // that the byte right before the position is the top one), equal leading bytes of their XOR, at most maxBack
 DEV int seq_backext4(const uint8_t* __restrict__ src, int pos, int cnd, int maxBack, bool* more)
 {
-    const int pa = max_(pos - 4, 0), ca = max_(cnd - 4, 0);
+    // (a match that starts at the anchor cannot catch up, maxBack == 0: its candidate-side load -- a random sector, the bytes this
+    // pass is bound by -- goes to the position's dword instead, which the neighbouring lanes read anyway; the result is 0 either way)
+    const int pa = max_(pos - 4, 0), ca = maxBack > 0 ? max_(cnd - 4, 0) : pa;
     const uint32_t xa = ld32u(src + pa) << ((8 * (4 - (pos - pa))) & 31), xc = ld32u(src + ca) << ((8 * (4 - (cnd - ca))) & 31);
     const uint32_t x = xa ^ xc;
     const int e4 = x ? (__builtin_clz(x) >> 3) : 4;

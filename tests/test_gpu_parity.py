@@ -297,8 +297,8 @@ def test_gpu_host_calls_in_many_chunks(orc, monkeypatch):
     e.close()
 
 
-@pytest.mark.parametrize("budget_mib", [0, 40])
-def test_gpu_duplex_call(orc, monkeypatch, budget_mib):
+@pytest.mark.parametrize("budget_mib,bsz,bsz_b", [(0, 4 << 20, 4 << 20), (40, 4 << 20, 4 << 20), (0, 256 << 10, 64 << 10)])
+def test_gpu_duplex_call(orc, monkeypatch, budget_mib, bsz, bsz_b):
     """plz4hip_dev_duplex_records == plz4hip_dev_encode_records of one batch + plz4hip_dev_decode_records of another (k_l1_duplex:
     one parser wave and two decoder waves per workgroup): the records are the oracle's, the decoded blocks the other batch's
     plaintext with every status OK -- a damaged record reports as it does in the plain call -- also when the encode side runs in
@@ -308,12 +308,11 @@ def test_gpu_duplex_call(orc, monkeypatch, budget_mib):
     if budget_mib:
         monkeypatch.setenv("PLZ4HIP_L1_BUDGET_MIB", str(budget_mib))
     e = Engine(0)
-    bsz = 4 << 20
     dataA = synth.make("M", 6 * bsz + 4321, bsz)
-    dataB = synth.make("T", 9 * bsz + 77, bsz)
-    nA = (dataA.size + bsz - 1) // bsz; nB = (dataB.size + bsz - 1) // bsz
-    wantA = orc.frame_encode(dataA, 7, block_checksum=True, content_checksum=False)[7:-4]
-    recsB = [orc.block_record(dataB[o:o + bsz], bsz, True) for o in range(0, dataB.size, bsz)]
+    dataB = synth.make("T", 9 * bsz_b + 77, bsz_b)
+    nA = (dataA.size + bsz - 1) // bsz; nB = (dataB.size + bsz_b - 1) // bsz_b
+    wantA = np.concatenate([orc.block_record(dataA[o:o + bsz], bsz, True) for o in range(0, dataA.size, bsz)])
+    recsB = [orc.block_record(dataB[o:o + bsz_b], bsz_b, True) for o in range(0, dataB.size, bsz_b)]
     recsB[4] = recsB[4].copy(); recsB[4][100] ^= 0x40                       # block 4: its checksum no longer matches
     offB = np.zeros(nB + 1, dtype=np.int64); offB[1:] = np.cumsum([r.size for r in recsB])
     dev = torch.device("cuda:0")
@@ -325,7 +324,7 @@ def test_gpu_duplex_call(orc, monkeypatch, budget_mib):
     d_bodyA = torch.empty(dataA.size + 8 * nA, dtype=torch.uint8, device=dev)
     d_bodyB = torch.from_numpy(np.concatenate(recsB)).to(dev)
     d_offB = torch.from_numpy(offB).to(dev)
-    d_out = torch.zeros(nB * bsz, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(nB * bsz_b, dtype=torch.uint8, device=dev)
     d_res = torch.zeros(nB, dtype=torch.int32, device=dev)
     d_st = torch.full((nB,), -9, dtype=torch.int32, device=dev)
     s = torch.cuda.current_stream().cuda_stream
@@ -339,27 +338,27 @@ def test_gpu_duplex_call(orc, monkeypatch, budget_mib):
     def check_decode():
         st = d_st.cpu().numpy(); res = d_res.cpu().numpy(); out = d_out.cpu().numpy()
         for i in range(nB):
-            blk = dataB[i * bsz:(i + 1) * bsz]
+            blk = dataB[i * bsz_b:(i + 1) * bsz_b]
             if i == 4:
                 assert st[i] != 0                                            # (PLZ4HIP_BLK_HASH_MISMATCH)
             else:
-                assert st[i] == 0 and res[i] == blk.size and np.array_equal(out[i * bsz:i * bsz + blk.size], blk), i
+                assert st[i] == 0 and res[i] == blk.size and np.array_equal(out[i * bsz_b:i * bsz_b + blk.size], blk), i
 
     e.dev_duplex_records(d_src.data_ptr(), dataA.size, bsz, True, d_stage.data_ptr(), d_len.data_ptr(),
-                         d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+                         d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz_b, True, d_out.data_ptr(), bsz_b, bsz_b, d_res.data_ptr(), d_st.data_ptr(), s)
     check_encode(); check_decode()
     want_st = d_st.clone()
-    e.dev_decode_records(d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+    e.dev_decode_records(d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz_b, True, d_out.data_ptr(), bsz_b, bsz_b, d_res.data_ptr(), d_st.data_ptr(), s)
     torch.cuda.synchronize()
     assert torch.equal(want_st, d_st)                                        # the same status codes as the plain call
     # either side empty
     d_stage.zero_(); d_len.zero_(); d_out.zero_(); d_st.fill_(-9)
     e.dev_duplex_records(d_src.data_ptr(), dataA.size, bsz, True, d_stage.data_ptr(), d_len.data_ptr(),
-                         d_bodyB.data_ptr(), d_offB.data_ptr(), 0, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+                         d_bodyB.data_ptr(), d_offB.data_ptr(), 0, bsz_b, True, d_out.data_ptr(), bsz_b, bsz_b, d_res.data_ptr(), d_st.data_ptr(), s)
     check_encode()
     assert int((d_st != -9).sum().item()) == 0
     e.dev_duplex_records(d_src.data_ptr(), 0, bsz, True, d_stage.data_ptr(), d_len.data_ptr(),
-                         d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+                         d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz_b, True, d_out.data_ptr(), bsz_b, bsz_b, d_res.data_ptr(), d_st.data_ptr(), s)
     torch.cuda.synchronize()
     check_decode()
     e.close()
