@@ -1071,6 +1071,9 @@ struct plz4hip_ctx {
     // ordered across streams on the device like the HC workspaces
     L1Ws         l1;
     hipEvent_t   l1Done = nullptr; hipStream_t l1Stream = nullptr; bool l1Pending = false;
+    // levels 3..11 on independent blocks: the list builder of the next group of blocks runs on this stream beside the walk of the
+    // current one (launch_hc)
+    hipStream_t  hcBuildStream = nullptr; hipEvent_t evHcFork = nullptr, evHcHist = nullptr, evHcChain[2] = {nullptr, nullptr}, evHcFree[2] = {nullptr, nullptr};
     int32_t*     d_lenCopy = nullptr; int lenCopyCap = 0;      // plz4hip_dev_compress: the sanitised block lengths of the last call
 };
 
@@ -1349,16 +1352,70 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         a.h12Gather = 12; a.h12Idle = 16;
         if (const char* v = getenv("PLZ4HIP_HC12_GATHER")) a.h12Gather = atoi(v);
         if (const char* v = getenv("PLZ4HIP_HC12_IDLE")) a.h12Idle = atoi(v);
-        const int nGroups = (nb + pl.group - 1) / pl.group;
-        const int per = (nb + nGroups - 1) / nGroups;                     // groups of equal size (<= pl.group)
+        int nGroups = (nb + pl.group - 1) / pl.group;
+        int per = (nb + nGroups - 1) / nGroups;                           // groups of equal size (<= pl.group)
         HIPCHK(c, hipMemsetAsync(a.h12Err, 0, 4, s));                      // the give-up flag is per call (k_hc12_parse reports it per block)
-        for (int g0 = 0; g0 < nb; g0 += per) {
+        // Levels 3..11: the list builder is one wave per CU around 128 KiB of LDS (0.3 s per 2048 blocks with the chip all but idle),
+        // the walk needs no LDS.  A call of enough blocks therefore runs in at least four groups over the two halves of the
+        // workspace, the builder of group g+1 on a second stream beside the walk of group g (which leaves it a wave slot per CU);
+        // the histogram of group g+1 (1024-thread workgroups that would not find room beside the walk) runs between two walks.
+        int overlapMin = 2048;
+        if (const char* v = getenv("PLZ4HIP_HC_OVERLAP_MIN")) overlapMin = atoi(v);           // tests: the pipeline on a handful of blocks
+        const bool overlap = lazy && nb >= overlapMin && nb >= 2 && getenv("PLZ4HIP_HC_OVERLAP_OFF") == nullptr;
+        if (overlap) {
+            int tgt = pl.group / 2 < (nb + 3) / 4 ? pl.group / 2 : (nb + 3) / 4;
+            if (tgt < 1) tgt = 1;
+            nGroups = (nb + tgt - 1) / tgt;
+            per = (nb + nGroups - 1) / nGroups;
+            if (!c->hcBuildStream) HIPCHK(c, hipStreamCreateWithFlags(&c->hcBuildStream, hipStreamNonBlocking));
+            for (hipEvent_t* ev : {&c->evHcFork, &c->evHcHist, &c->evHcChain[0], &c->evHcChain[1], &c->evHcFree[0], &c->evHcFree[1]})
+                if (!*ev) HIPCHK(c, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+        }
+        // the workspace pointers of the half a group uses: every per-block array moved on by k blocks
+        const auto half = [&](CodecArgs x, int k) {
+            x.h12Chain += (int64_t)k * x.h12ChainStride; x.h12Rank += (int64_t)k * x.h12ChainStride; x.h12List += (int64_t)k * (x.h12ChainStride + 8);
+            x.h12Offsets += (size_t)k * kHcHashEntries; x.h12F += (int64_t)k * x.h12FStride; x.l1Seq += (int64_t)k * x.l1SeqStride;
+            x.l1Info += k; x.l1ChunkBytes += (int64_t)k * x.l1MaxChunks; x.l1ChunkOff += (int64_t)k * x.l1MaxChunks;
+            x.lzRec += (int64_t)k * x.lzRecStride; x.lzBridge += (int64_t)k * x.lzRecStride;
+            x.lzMeta += (int64_t)k * kLzMaxSegs; x.lzStarts += (int64_t)k * kLzMaxSegs * kLzStarts; x.lzPieces += (int64_t)k * 2 * kLzMaxSegs;
+            return x;
+        };
+        const auto build = [&](hipStream_t st, CodecArgs x, bool hist, bool chain) -> int {
+            hipError_t e2;
+            if (hist)  { x.queue = next_queue(c, st, &e2); HIPCHK(c, e2); hipLaunchKernelGGL(k_hc12_hist, dim3(grid_for(x.nBlocks, c->cus)), dim3(1024), 0, st, x); }
+            if (chain) { x.queue = next_queue(c, st, &e2); HIPCHK(c, e2); hipLaunchKernelGGL(k_hc12_chain, dim3(grid_for(x.nBlocks, c->cus)), dim3(64), 0, st, x); }
+            return PLZ4HIP_OK;
+        };
+        const CodecArgs a0 = a;
+        if (overlap) {
+            hipStream_t sb = c->hcBuildStream;
+            HIPCHK(c, hipEventRecord(c->evHcFork, s));
+            HIPCHK(c, hipStreamWaitEvent(sb, c->evHcFork, 0));
+            CodecArgs x = half(a0, 0); x.blk0 = 0; x.nBlocks = nb < per ? nb : per;
+            if (int rc = build(sb, x, true, true)) return rc;
+            HIPCHK(c, hipEventRecord(c->evHcChain[0], sb));
+            if (nGroups > 1) {
+                x = half(a0, per); x.blk0 = per; x.nBlocks = nb - per < per ? nb - per : per;
+                if (int rc = build(sb, x, true, false)) return rc;
+                HIPCHK(c, hipEventRecord(c->evHcHist, sb));
+            }
+        }
+        for (int g0 = 0, gi = 0; g0 < nb; g0 += per, ++gi) {
             const int ng = nb - g0 < per ? nb - g0 : per;
+            if (overlap) a = half(a0, (gi & 1) * per);
             a.blk0 = g0; a.nBlocks = ng;
-            a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-            hipLaunchKernelGGL(k_hc12_hist, dim3(grid_for(ng, c->cus)), dim3(1024), 0, s, a);
-            a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-            hipLaunchKernelGGL(k_hc12_chain, dim3(grid_for(ng, c->cus)), dim3(64), 0, s, a);
+            if (overlap) {
+                hipStream_t sb = c->hcBuildStream;
+                HIPCHK(c, hipStreamWaitEvent(s, c->evHcChain[gi & 1], 0));
+                if (gi + 1 < nGroups) {
+                    HIPCHK(c, hipStreamWaitEvent(s, c->evHcHist, 0));           // the next group's histogram is done: its builder starts now
+                    CodecArgs x = half(a0, ((gi + 1) & 1) * per); x.blk0 = g0 + per; x.nBlocks = nb - x.blk0 < per ? nb - x.blk0 : per;
+                    if (int rc = build(sb, x, false, true)) return rc;
+                    HIPCHK(c, hipEventRecord(c->evHcChain[(gi + 1) & 1], sb));
+                }
+            } else {
+                if (int rc = build(s, a, true, true)) return rc;
+            }
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);
             if (!lazy) hipLaunchKernelGGL(k_hc12_search, dim3(grid_for(ng, c->cus)), dim3(1024), 0, s, a);
             a.queue = next_queue(c, s, &e); HIPCHK(c, e);
@@ -1376,7 +1433,8 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
                     a.queue = next_queue(c, s, &e); HIPCHK(c, e);
                     hipLaunchKernelGGL(k_hc12_stitch, dim3(grid_for(ng, c->h12SegWaves)), dim3(64), 0, s, a);
                 } else {
-                const int lzWaves = a.level >= 10 && c->hcWaves < c->hcLazyWaves ? c->hcWaves : c->hcLazyWaves;   // (a price table per wave)
+                int lzWaves = a.level >= 10 && c->hcWaves < c->hcLazyWaves ? c->hcWaves : c->hcLazyWaves;   // (a price table per wave)
+                if (overlap && lzWaves > 2 * c->cus) lzWaves -= c->cus;                    // a wave slot (and its registers) per CU for the builder
                 hipLaunchKernelGGL(k_hc_lazy, dim3(grid_for(ng * a.lzSegs, lzWaves)), dim3(64), 0, s, a);
                 a.queue = next_queue(c, s, &e); HIPCHK(c, e);
                 hipLaunchKernelGGL(k_hc_stitch, dim3(grid_for(ng, lzWaves)), dim3(64), 0, s, a);
@@ -1391,6 +1449,15 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
                 if (!rawMode && a.blockChecksum) hipLaunchKernelGGL(k_l1_finish, dim3((ng + 3) / 4), dim3(256), 0, s, a);
             }
             HIPCHK(c, hipGetLastError());
+            if (overlap && gi + 2 < nGroups) {
+                // this half is free again: the histogram of the group after next may overwrite it
+                hipStream_t sb = c->hcBuildStream;
+                HIPCHK(c, hipEventRecord(c->evHcFree[gi & 1], s));
+                HIPCHK(c, hipStreamWaitEvent(sb, c->evHcFree[gi & 1], 0));
+                CodecArgs x = half(a0, (gi & 1) * per); x.blk0 = g0 + 2 * per; x.nBlocks = nb - x.blk0 < per ? nb - x.blk0 : per;
+                if (int rc = build(sb, x, true, false)) return rc;
+                HIPCHK(c, hipEventRecord(c->evHcHist, sb));
+            }
         }
     } else {
         if (int rc = ensure_hc(c)) return rc;
@@ -1682,6 +1749,8 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     if (c->l1Done) hipEventDestroy(c->l1Done);
     if (c->hcDone) hipEventDestroy(c->hcDone);
     if (c->hashStream) { hipStreamSynchronize(c->hashStream); hipStreamDestroy(c->hashStream); }
+    if (c->hcBuildStream) { hipStreamSynchronize(c->hcBuildStream); hipStreamDestroy(c->hcBuildStream); }
+    for (hipEvent_t ev : {c->evHcFork, c->evHcHist, c->evHcChain[0], c->evHcChain[1], c->evHcFree[0], c->evHcFree[1]}) if (ev) hipEventDestroy(ev);
     delete c;
 }
 

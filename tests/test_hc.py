@@ -383,6 +383,52 @@ def test_gpu_hc_chain_and_lists_in_groups(ref, orc, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nblk", [11, 2])
+def test_gpu_hc_builder_beside_the_walk(ref, orc, monkeypatch, nblk):
+    """Levels 3..11 of a large call run in four or more groups over the two halves of the workspace, the list builder of the
+    next group on a second stream beside the walk of the current one (launch_hc).  The pipeline switched on for a handful of
+    blocks (PLZ4HIP_HC_OVERLAP_MIN): records and raw blocks as the reference's, twice in a row on one ctx (the halves and
+    the events are reused), device-resident call included."""
+    import torch
+    from plz4_amd._native import Engine
+    bsz = 256 << 10
+    data = synth.make("M", (nblk - 1) * bsz + 4321, bsz)
+    srcs = [data[o:o + bsz] for o in range(0, data.size, bsz)]
+    monkeypatch.setenv("PLZ4HIP_HC_OVERLAP_MIN", "2")
+    eng = Engine(0)
+    for lvl in (3, 9, 10, 11, 5):
+        want = [ref.compress_hc(s, bsz, lvl) for s in srcs]
+        for rep in range(2):
+            recs = eng.encode_records(srcs, bsz, True, level=lvl)
+            for i, (s, rec, (n, c)) in enumerate(zip(srcs, recs, want)):
+                if n:
+                    assert not (rec[3] & 0x80) and np.array_equal(rec[4:-4], c[:n]), (lvl, rep, i)
+                else:
+                    assert rec[3] & 0x80 and np.array_equal(rec[4:-4], s), (lvl, rep, i)
+        res, outs = eng.compress_batch(srcs, [orc.bound(s.size) for s in srcs], level=lvl)
+        for i, s in enumerate(srcs):
+            n2, c2 = ref.compress_hc(s, orc.bound(s.size), lvl)
+            assert int(res[i]) == n2 and np.array_equal(outs[i], c2), (lvl, i)
+    # device-resident, on the caller's stream
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(data).to(dev); stride = eng.stage_stride(bsz)
+    d_stage = torch.zeros(len(srcs) * stride, dtype=torch.uint8, device=dev); d_len = torch.zeros(len(srcs), dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        eng.dev_encode_records(d_src.data_ptr(), data.size, bsz, True, d_stage.data_ptr(), d_len.data_ptr(), st.cuda_stream, level=9)
+    st.synchronize()
+    lens = d_len.cpu().numpy(); stage = d_stage.cpu().numpy()
+    for i, s in enumerate(srcs):
+        n, c = ref.compress_hc(s, bsz, 9)
+        rec = stage[i * stride:i * stride + int(lens[i])]
+        if n:
+            assert not (rec[3] & 0x80) and np.array_equal(rec[4:-4], c[:n]), i
+        else:
+            assert rec[3] & 0x80 and np.array_equal(rec[4:-4], s), i
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_gpu_hc12_block_sizes_beyond_the_frame_path(ref, orc):
     """The raw block API takes blocks of any size: 5 MiB runs the three-phase kernels (positions beyond 22 bits), 9 MiB falls back
     to the one-thread-per-block kernel (the three-phase writer packs positions into 23 bits); a batch of ragged sizes too."""
