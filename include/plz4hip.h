@@ -29,7 +29,10 @@
  * per input byte of the blocks in flight (chain, per-hash lists, sequence records of the segments), level 12 22.5 (the search results as well), level 2 2.25, out
  * of a quarter of the device memory that is free when the call arrives, at most 64 GiB; a call whose blocks do not fit runs in
  * groups.  A caller that owns the GPU raises the budget with PLZ4HIP_HC_BUDGET_GIB (these kernels live on blocks in flight).
- * Other environment switches, for tests and experiments only: PLZ4HIP_HC_SEGS / PLZ4HIP_HC_MIN_SEG (segments a block is walked
+ * Other environment switches, for tests and experiments only: PLZ4HIP_HC_OVERLAP_OFF / _MIN / _GROUPS (levels 3..11: a call of 2048
+ * blocks or more runs in four or more groups, the list builder of the next group on a second stream of the ctx beside the walk
+ * of the current one), PLZ4HIP_DUPLEX=P,D / PLZ4HIP_DUPLEX_PRIO (parser + decoder waves per workgroup of the duplex call),
+ * PLZ4HIP_HC_SEGS / PLZ4HIP_HC_MIN_SEG (segments a block is walked
  * in at levels 3..11, default up to 512 of at least 8 KiB), PLZ4HIP_HC_LAZY_OFF / PLZ4HIP_HC_MID_OFF / PLZ4HIP_HC12_OFF / PLZ4HIP_L1_FUSED
  * (the one-kernel paths of rounds 1-2 instead), PLZ4HIP_HOST_CHUNK_MB, PLZ4HIP_VERBOSE.
  */

@@ -1363,7 +1363,9 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         if (const char* v = getenv("PLZ4HIP_HC_OVERLAP_MIN")) overlapMin = atoi(v);           // tests: the pipeline on a handful of blocks
         const bool overlap = lazy && nb >= overlapMin && nb >= 2 && getenv("PLZ4HIP_HC_OVERLAP_OFF") == nullptr;
         if (overlap) {
-            int tgt = pl.group / 2 < (nb + 3) / 4 ? pl.group / 2 : (nb + 3) / 4;
+            int want = 4;
+            if (const char* v = getenv("PLZ4HIP_HC_OVERLAP_GROUPS")) { want = atoi(v); if (want < 2) want = 2; }
+            int tgt = pl.group / 2 < (nb + want - 1) / want ? pl.group / 2 : (nb + want - 1) / want;
             if (tgt < 1) tgt = 1;
             nGroups = (nb + tgt - 1) / tgt;
             per = (nb + nGroups - 1) / nGroups;
