@@ -1361,7 +1361,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         // the histogram of group g+1 (1024-thread workgroups that would not find room beside the walk) runs between two walks.
         int overlapMin = 2048;
         if (const char* v = getenv("PLZ4HIP_HC_OVERLAP_MIN")) overlapMin = atoi(v);           // tests: the pipeline on a handful of blocks
-        const bool overlap = lazy && nb >= overlapMin && nb >= 2 && getenv("PLZ4HIP_HC_OVERLAP_OFF") == nullptr;
+        const bool overlap = lazy && nb >= overlapMin && nb >= 2 && pl.group >= 2 && getenv("PLZ4HIP_HC_OVERLAP_OFF") == nullptr;   // (two groups' worth of workspace)
         if (overlap) {
             int want = 4;
             if (const char* v = getenv("PLZ4HIP_HC_OVERLAP_GROUPS")) { want = atoi(v); if (want < 2) want = 2; }
