@@ -1389,21 +1389,32 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             return PLZ4HIP_OK;
         };
         const CodecArgs a0 = a;
+        // The groups.  With the builder beside the walk only the first group's builder is exposed, so the groups start small and
+        // double (a builder takes about half the time of the walk over the same blocks: the next group's is done when this
+        // group's walk is) until they have the full size.
+        std::vector<int> gStart, gSize;
+        for (int at = 0, sz = overlap ? (per / 8 > 0 ? per / 8 : 1) : per; at < nb; ) {
+            const int n_ = nb - at < sz ? nb - at : sz;
+            gStart.push_back(at); gSize.push_back(n_);
+            at += n_;
+            sz = sz * 2 < per ? sz * 2 : per;
+        }
+        nGroups = (int)gStart.size();
         if (overlap) {
             hipStream_t sb = c->hcBuildStream;
             HIPCHK(c, hipEventRecord(c->evHcFork, s));
             HIPCHK(c, hipStreamWaitEvent(sb, c->evHcFork, 0));
-            CodecArgs x = half(a0, 0); x.blk0 = 0; x.nBlocks = nb < per ? nb : per;
+            CodecArgs x = half(a0, 0); x.blk0 = gStart[0]; x.nBlocks = gSize[0];
             if (int rc = build(sb, x, true, true)) return rc;
             HIPCHK(c, hipEventRecord(c->evHcChain[0], sb));
             if (nGroups > 1) {
-                x = half(a0, per); x.blk0 = per; x.nBlocks = nb - per < per ? nb - per : per;
+                x = half(a0, per); x.blk0 = gStart[1]; x.nBlocks = gSize[1];
                 if (int rc = build(sb, x, true, false)) return rc;
                 HIPCHK(c, hipEventRecord(c->evHcHist, sb));
             }
         }
-        for (int g0 = 0, gi = 0; g0 < nb; g0 += per, ++gi) {
-            const int ng = nb - g0 < per ? nb - g0 : per;
+        for (int gi = 0; gi < nGroups; ++gi) {
+            const int g0 = gStart[gi], ng = gSize[gi];
             if (overlap) a = half(a0, (gi & 1) * per);
             a.blk0 = g0; a.nBlocks = ng;
             if (overlap) {
@@ -1411,7 +1422,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
                 HIPCHK(c, hipStreamWaitEvent(s, c->evHcChain[gi & 1], 0));
                 if (gi + 1 < nGroups) {
                     HIPCHK(c, hipStreamWaitEvent(s, c->evHcHist, 0));           // the next group's histogram is done: its builder starts now
-                    CodecArgs x = half(a0, ((gi + 1) & 1) * per); x.blk0 = g0 + per; x.nBlocks = nb - x.blk0 < per ? nb - x.blk0 : per;
+                    CodecArgs x = half(a0, ((gi + 1) & 1) * per); x.blk0 = gStart[gi + 1]; x.nBlocks = gSize[gi + 1];
                     if (int rc = build(sb, x, false, true)) return rc;
                     HIPCHK(c, hipEventRecord(c->evHcChain[(gi + 1) & 1], sb));
                 }
@@ -1456,7 +1467,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
                 hipStream_t sb = c->hcBuildStream;
                 HIPCHK(c, hipEventRecord(c->evHcFree[gi & 1], s));
                 HIPCHK(c, hipStreamWaitEvent(sb, c->evHcFree[gi & 1], 0));
-                CodecArgs x = half(a0, (gi & 1) * per); x.blk0 = g0 + 2 * per; x.nBlocks = nb - x.blk0 < per ? nb - x.blk0 : per;
+                CodecArgs x = half(a0, (gi & 1) * per); x.blk0 = gStart[gi + 2]; x.nBlocks = gSize[gi + 2];
                 if (int rc = build(sb, x, true, false)) return rc;
                 HIPCHK(c, hipEventRecord(c->evHcHist, sb));
             }
