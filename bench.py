@@ -35,21 +35,33 @@ POOL_BLOCKS = 16            # 64 MiB of unique T text generated on the host, til
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def committed_traffic(kernel: str, blocks: int):
-    """Bytes per launch that crossed the L2 boundary, from the committed rocprofv3 PMC passes (profiles/*_summary.json,
-    scripts/gpu_profile_r03.sh + scripts/summarize_profile.py; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes, plus
-    WRITE_SIZE).  The counters sit behind L2: hits in the Infinity Cache are in them, so this is an upper bound of the HBM
-    traffic.  None when no profile of this exact workload size is committed -- PMC counters cannot be read from inside the timed
-    process."""
-    import glob
+def committed_traffic(kernel: str, blocks: int, level: int = 1):
+    """Bytes per STEP that crossed the L2 boundary for the kernels named (joined by +), from the committed rocprofv3 PMC passes
+    (profiles/*_summary.json, scripts/gpu_profile_r0*.sh + scripts/summarize_profile.py; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    §HBM prescribes, plus WRITE_SIZE).  The counters sit behind L2: hits in the Infinity Cache are in them, so this is an upper
+    bound of the HBM traffic.  A summary counts only if it was taken at this workload size AND this level, and only if it holds
+    per-step totals (an HC call launches its kernels once per group of blocks, so a per-launch average times one is not a step) --
+    or, for summaries older than that field, if every kernel asked for ran exactly once per step there (level 1).  None otherwise:
+    PMC counters cannot be read from inside the timed process, and another level's figure is worse than none."""
+    import glob, re
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_summary.json"))):
         try:
             d = json.load(open(f))
-            key = lambda e: e.get("l2_miss_traffic_bytes", e.get("hbm_traffic_bytes_fetch_x2"))      # (second name: rounds 1-2)
-            ks = [k for k in kernel.split("+") if key(d["kernels"].get(k, {})) is not None]
-            if d.get("blocks_per_gpu") == blocks and len(ks) == len(kernel.split("+")):
-                best = {"bytes": sum(key(d["kernels"][k]) for k in ks), "source": os.path.basename(f)}
+            lv = d.get("level")
+            if lv is None:                                                   # rounds 1-3: the level is in the tag
+                m = re.search(r"level(\d+)", d.get("tag", ""))
+                lv = int(m.group(1)) if m else 1
+            if d.get("blocks_per_gpu") != blocks or lv != level:
+                continue
+            ks = kernel.split("+")
+            ent = [d["kernels"].get(k, {}) for k in ks]
+            if all("l2_miss_traffic_bytes_per_step" in e for e in ent):
+                best = {"bytes": sum(e["l2_miss_traffic_bytes_per_step"] for e in ent), "source": os.path.basename(f), "per": "step"}
+            elif level == 1:
+                key = lambda e: e.get("l2_miss_traffic_bytes", e.get("hbm_traffic_bytes_fetch_x2"))  # (second name: rounds 1-2)
+                if all(key(e) is not None for e in ent):
+                    best = {"bytes": sum(key(e) for e in ent), "source": os.path.basename(f), "per": "launch (one launch per step)"}
         except Exception:
             pass
     return best
@@ -475,9 +487,11 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         enc_ms, cmp_ms, gat_ms, dec_ms = seg.mean(axis=0).tolist()
         mib = S / 2**20
-        # level 12 is one ABI call of four kernels (hist, chain, search, parse; lz4hc12_device.inl): they are timed together
+        # level 12 is one ABI call of its phases (hist, chain, search, then the parser in segments: seg, stitch, gather) and the emit
+        # kernels it shares with level 1 (lz4hc12_device.inl): they are timed together
         # level 1 is one ABI call of five kernels (parse, sizes, scan, write, finish; lz4_seq_device.inl), timed together as well
-        enc_kernel = "k_l1_parse+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if args.level == 1 else ("k_hc12_hist+k_hc12_chain+k_hc12_search+k_hc12_parse" if args.level >= 12 else
+        enc_kernel = "k_l1_parse+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if args.level == 1 else (
+                      "k_hc12_hist+k_hc12_chain+k_hc12_search+k_hc12_seg+k_hc12_stitch+k_hc_gather+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if args.level >= 12 else
                       ("k_hc12_hist+k_hc12_chain+k_hc_lazy+k_hc_stitch+k_hc_gather+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if 3 <= args.level <= 11 else
                        ("k_hc_mid+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish" if args.level == 2 else "k_encode_rec_hc")))
         ach_enc = (S + C_bytes) / (enc_ms * 1e-3) / 1e9
@@ -498,7 +512,7 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "k_decode_rec", "achieved": round(ach_dec, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(ach_dec / HBM_PEAK_GBS, 5), "traffic": None},
             }
-            t = committed_traffic("k_decode_rec", B)
+            t = committed_traffic("k_decode_rec", B, args.level)
             if t:
                 line["roofline"]["traffic"] = t["bytes"]; line["roofline"]["traffic_source"] = t["source"]
             os.write(real_stdout, (json.dumps(line) + "\n").encode())
@@ -507,7 +521,7 @@ def main():
             eng.close()
             return
         out = {
-            "metric": "MiB/s enc+dec, 4MiB independent blocks, level %d, block-checksum on" % args.level,
+            "metric": "MiB/s enc+dec, 4MiB independent blocks, level %d, block-checksum on%s" % (args.level, " (duplex step)" if duplex else ""),
             "value": round(world * mib / (ms_step * 1e-3), 1),
             "unit": "MiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -519,7 +533,8 @@ def main():
                                    "checksum off; step = encode->frame body->decode, inputs resident in HBM"
                                    % (B, args.kind, args.level),
                        "blocks_per_gpu": B, "block_bytes": BSZ, "pipeline_parts": NP, "stored_ratio": round(C_bytes / S, 4),
-                       "sharding": "block i -> rank i mod N" if world > 1 else "single GPU"},
+                       "sharding": "block i -> rank i mod N" if world > 1 else "single GPU",
+                       **({"hc_workspace_budget_gib": int(os.environ["PLZ4HIP_HC_BUDGET_GIB"])} if args.level > 1 else {})},
             "enc_MiBps_per_gpu": round(mib / (enc_ms * 1e-3), 1),
             "dec_MiBps_per_gpu": round(mib / (dec_ms * 1e-3), 1),
             "ms": {"encode_kernel": round(enc_ms, 3), "scan_compact": round(cmp_ms, 3),
@@ -559,13 +574,13 @@ def main():
                     "roofline_decode": {"bound": "hbm", "kernel": "k_decode_rec", "achieved": round(a_d, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": round(a_d / HBM_PEAK_GBS, 5), "traffic": None}}
                 for key, kern in (("roofline", k_e), ("roofline_decode", "k_decode_rec")):
-                    t = committed_traffic(kern, B)
+                    t = committed_traffic(kern, B, 1)
                     if t:
                         out["serial_step"][key]["traffic"] = t["bytes"]; out["serial_step"][key]["traffic_source"] = t["source"]
         for key, kern in (("roofline", enc_kernel), ("roofline_decode", "k_decode_rec")):
-            t = committed_traffic(kern, B) if key in out else None
+            t = committed_traffic(kern, B, args.level) if key in out else None
             if t:
-                out[key]["traffic"] = t["bytes"]; out[key]["traffic_source"] = t["source"]
+                out[key]["traffic"] = t["bytes"]; out[key]["traffic_source"] = t["source"]; out[key]["traffic_per"] = t["per"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool, level=args.level, check=check_pairs)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -230,10 +230,15 @@ int plz4hip_dev_duplex_records(plz4hip_ctx* ctx, const void* src, int64_t srcByt
                                void* dst, int64_t dstStride, int dstCap, int32_t* result, int32_t* status, void* stream);
 
 /* Raw LZ4 blocks on the device (no record framing): block i = src + i*srcStride (srcLen[i] bytes) ->
- * dst + i*dstStride (capacity dstCap[i]); result[i] as in A, levels 1..12.  srcLen/dstCap/result are device arrays; maxLen
- * (host value, >= every srcLen[i]) sizes the HC workspace and is only read for levels 2..12.
- * HC levels (here and in plz4hip_dev_encode_records) work in per-ctx workspaces: jobs enqueued on different streams of one ctx
- * are ordered behind each other on the device (an event wait, no host block); they never overlap. */
+ * dst + i*dstStride (capacity dstCap[i]); result[i] as in A, levels 1..12.  srcLen/dstCap/result are device arrays.
+ * maxLen is a host value the per-block workspaces are sized from, at EVERY level: it must be >= every srcLen[i]; a block whose
+ * device-side length is outside [0, maxLen] is not touched and gets result[i] = PLZ4HIP_E_ARG (its neighbours are unaffected).
+ * maxLen <= 0 means "unknown to the host": allowed at level 1 only, where it selects the one-kernel encoder that needs no
+ * workspace (levels 2..12 return PLZ4HIP_E_ARG for the call).  A level-1 caller with a loose or stale positive maxLen therefore
+ * gets per-block errors, not slower output: pass 0 rather than a guess.
+ * The staged level-1 call and the HC levels (here and in plz4hip_dev_encode_records) work in per-ctx workspaces and read a
+ * per-ctx sanitised copy of srcLen: jobs enqueued on different streams of one ctx are ordered behind each other on the device
+ * (an event wait, no host block); they never overlap. */
 int plz4hip_dev_compress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
                          void* dst, int64_t dstStride, const int32_t* dstCap, int level, int maxLen, int32_t* result, void* stream);
 int plz4hip_dev_decompress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,

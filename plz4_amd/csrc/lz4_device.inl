@@ -44,7 +44,11 @@ enum : int {
     kMinMatch = 4, kMfLimit = 12, kLastLiterals = 5, kMinLength = 13,
     k64KLimit = 65536 + kMfLimit - 1,            // lz4.c:710
     kMaxInput = 0x7E000000,                      // lz4.h:214
+#if defined(PLZ4_EXP_TABBITS)
+    kHashBytes = 4 << PLZ4_EXP_TABBITS           // EXPERIMENT (scripts/exp_smalltab.sh): a smaller table, valid but different output
+#else
     kHashBytes = 16384                           // LZ4_HASHTABLESIZE, lz4.h:696
+#endif
 };
 static constexpr uint32_t kMaxDist = 65535u;     // lz4.h:674
 
@@ -263,7 +267,11 @@ static inline uint32_t xxh32_stream_sum(const XxhStream& st)
 template <bool U16> DEV uint32_t seq_hash(uint64_t seq8)
 {
     if (U16) return ((uint32_t)seq8 * 2654435761u) >> 19;                   // hash4, 13 bits
+#if defined(PLZ4_EXP_TABBITS)
+    return (uint32_t)(((seq8 << 24) * 889523592379ull) >> (64 - PLZ4_EXP_TABBITS));
+#else
     return (uint32_t)(((seq8 << 24) * 889523592379ull) >> 52);              // hash5, 12 bits
+#endif
 }
 template <bool U16> DEV uint32_t tab_get(const void* t, uint32_t h) { return U16 ? (uint32_t)((const uint16_t*)t)[h] : ((const uint32_t*)t)[h]; }
 template <bool U16> DEV void     tab_put(void* t, uint32_t h, uint32_t v) { if (U16) ((uint16_t*)t)[h] = (uint16_t)v; else ((uint32_t*)t)[h] = v; }

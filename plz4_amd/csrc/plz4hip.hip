@@ -942,7 +942,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 // (P parser waves + D decoder waves per workgroup: experiment switch PLZ4HIP_DUPLEX="P,D"; PRIO: the parser waves' s_setprio,
 // PLZ4HIP_DUPLEX_PRIO)
 constexpr int duplex_wgs_per_cu(int P, int D) { return (160 * 1024) / (P * kHashBytes + D * kDecLdsBytes); }
+#if defined(PLZ4_EXP_DUPLEX_EU)
+constexpr int duplex_waves_per_eu(int P, int D) { return PLZ4_EXP_DUPLEX_EU; }       // EXPERIMENT: forced occupancy target
+#else
 constexpr int duplex_waves_per_eu(int P, int D) { return ((P + D) * duplex_wgs_per_cu(P, D) + 3) / 4; }
+#endif
 template <int P, int D, int PRIO> __global__ __launch_bounds__(64 * (P + D))
 __attribute__((amdgpu_waves_per_eu(duplex_waves_per_eu(P, D), duplex_waves_per_eu(P, D))))
 void k_l1_duplex(CodecArgs a, CodecArgs d)
@@ -1074,7 +1078,10 @@ struct plz4hip_ctx {
     // levels 3..11 on independent blocks: the list builder of the next group of blocks runs on this stream beside the walk of the
     // current one (launch_hc)
     hipStream_t  hcBuildStream = nullptr; hipEvent_t evHcFork = nullptr, evHcHist = nullptr, evHcChain[2] = {nullptr, nullptr}, evHcFree[2] = {nullptr, nullptr};
-    int32_t*     d_lenCopy = nullptr; int lenCopyCap = 0;      // plz4hip_dev_compress: the sanitised block lengths of the last call
+    // plz4hip_dev_compress: the sanitised block lengths of the last call.  One job at a time like the workspaces: a call on another
+    // stream waits (on the device) for the event behind the last job's kernels before it overwrites the copy.
+    int32_t*     d_lenCopy = nullptr; int lenCopyCap = 0;
+    hipEvent_t   lenDone = nullptr; hipStream_t lenStream = nullptr; bool lenPending = false;
 };
 
 // == clz4.DictCtx (clz4.go:96-120): a private device copy of the last 64 KiB of the dictionary + the LZ4_loadDictSlow table.
@@ -1310,9 +1317,22 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
               const CodecArgs* rider = nullptr);
 
 // Enqueue one HC call of nb blocks (a: everything but queue / workspace filled in) on s.  rawMode: LZ4 blocks, else records.
+int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, bool* forked);
 int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode)
 {
     if (int rc = hc_enter(c, s)) return rc;
+    bool forked = false;
+    const int rc = launch_hc_body(c, s, a, nb, maxLen, rawMode, &forked);
+    // Whatever was enqueued uses the ctx's workspaces, also when the body left early: the call's stream joins the builder's
+    // stream (a completed body has done so group by group) and the event behind the job is recorded in any case, so that a
+    // following trim / destroy / HC job waits for kernels that may still run.
+    if (rc != PLZ4HIP_OK && forked && c->hcBuildStream && c->evHcFork
+        && hipEventRecord(c->evHcFork, c->hcBuildStream) == hipSuccess) (void)hipStreamWaitEvent(s, c->evHcFork, 0);
+    const int rc2 = hc_leave(c, s);
+    return rc != PLZ4HIP_OK ? rc : rc2;
+}
+int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, bool* forked)
+{
     hipError_t e;
     if (a.level == 2 && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_MID_OFF") == nullptr) {
         // level 2, independent blocks up to 4 MiB: the staged call of level 1 with the level-2 walk as its parser
@@ -1320,7 +1340,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         a.hcWork = c->d_hc;
         bool declined = false;
         if (int rc = launch_l1(c, s, a, nb, maxLen, rawMode, nullptr, &declined)) return rc;
-        if (!declined) return hc_leave(c, s);
+        if (!declined) return PLZ4HIP_OK;
     }
     const bool lazy = use_lazy(a, maxLen);
     if (lazy || use_h12(a, maxLen)) {
@@ -1404,6 +1424,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             hipStream_t sb = c->hcBuildStream;
             HIPCHK(c, hipEventRecord(c->evHcFork, s));
             HIPCHK(c, hipStreamWaitEvent(sb, c->evHcFork, 0));
+            *forked = true;
             CodecArgs x = half(a0, 0); x.blk0 = gStart[0]; x.nBlocks = gSize[0];
             if (int rc = build(sb, x, true, true)) return rc;
             HIPCHK(c, hipEventRecord(c->evHcChain[0], sb));
@@ -1565,7 +1586,7 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             HIPCHK(c, hipGetLastError());
         }
     }
-    return hc_leave(c, s);
+    return PLZ4HIP_OK;
 }
 
 // Enqueue one level-1 call of nb independent blocks without dictionary (a: everything but queue / workspace filled in) on s.
@@ -1657,7 +1678,19 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
 #undef DUPLEX_CASE
             if (!launched) return fail(c, PLZ4HIP_E_ARG, "PLZ4HIP_DUPLEX: not a built combination");
         }
+#if defined(PLZ4_EXP_TABBITS)
+        else {   // EXPERIMENT: W waves per workgroup, as many workgroups as the device holds
+            int W = 10; if (const char* ev = getenv("PLZ4HIP_EXP_W")) W = atoi(ev);
+#define EXP_CASE(WW) if (W == WW) { int per = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_l1_parse<WW>, 64 * WW, 0); \
+                if (getenv("PLZ4HIP_VERBOSE")) fprintf(stderr, "exp: W=%d workgroups per CU %d\n", WW, per); \
+                int wgs = c->cus * per; if (wgs * WW > ng) wgs = (ng + WW - 1) / WW; \
+                hipLaunchKernelGGL(k_l1_parse<WW>, dim3(wgs), dim3(64 * WW), 0, s, a); }
+            EXP_CASE(4) EXP_CASE(5) EXP_CASE(6) EXP_CASE(8) EXP_CASE(9) EXP_CASE(10) EXP_CASE(12) EXP_CASE(13) EXP_CASE(14) EXP_CASE(16)
+#undef EXP_CASE
+        }
+#else
         else ENC_LAUNCH(k_l1_parse, ng, c, s, a);
+#endif
         // emit: waves per block so that a small call still spreads over the chip
         int wg = (16384 / ng) / 4;
         if (wg > (maxChunks + 3) / 4) wg = (maxChunks + 3) / 4;
@@ -1759,6 +1792,7 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     if (c->l1Pending) hipEventSynchronize(c->l1Done);
     if (c->l1.d) hipFree(c->l1.d);
     if (c->d_lenCopy) hipFree(c->d_lenCopy);
+    if (c->lenDone) hipEventDestroy(c->lenDone);
     if (c->l1Done) hipEventDestroy(c->l1Done);
     if (c->hcDone) hipEventDestroy(c->hcDone);
     if (c->hashStream) { hipStreamSynchronize(c->hashStream); hipStreamDestroy(c->hashStream); }
@@ -1823,6 +1857,7 @@ int plz4hip_dev_compress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t s
             if (hipMalloc((void**)&c->d_lenCopy, (size_t)nBlocks * 4 + 1024) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "plz4hip_dev_compress: length copy");
             c->lenCopyCap = nBlocks + 256;
         }
+        if (c->lenPending && c->lenStream != s) HIPCHK(c, hipStreamWaitEvent(s, c->lenDone, 0));   // the last job's kernels still read the copy
         hipLaunchKernelGGL(k_check_len, dim3((nBlocks + 255) / 256), dim3(256), 0, s, srcLen, maxLen, nBlocks, c->d_lenCopy, result, 0);
         a.srcLen = c->d_lenCopy;
     }
@@ -1832,6 +1867,11 @@ int plz4hip_dev_compress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t s
     if (rc == PLZ4HIP_OK && maxLen > 0) {
         hipLaunchKernelGGL(k_check_len, dim3((nBlocks + 255) / 256), dim3(256), 0, s, srcLen, maxLen, nBlocks, c->d_lenCopy, result, 1);
         HIPCHK(c, hipGetLastError());
+    }
+    if (maxLen > 0) {                                                     // (also after a failed launch: whatever was enqueued reads the copy)
+        if (!c->lenDone) HIPCHK(c, hipEventCreateWithFlags(&c->lenDone, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->lenDone, s));
+        c->lenPending = true; c->lenStream = s;
     }
     return rc;
 }

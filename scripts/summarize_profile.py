@@ -5,6 +5,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 6144
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 note = sys.argv[3] if len(sys.argv) > 3 else None
+level = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 out = os.path.join(root, "profiles"); os.makedirs(out, exist_ok=True)
 
 import re
@@ -15,7 +16,7 @@ def short(k):
     return m.group(1) if m else None
 
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
-summary = {"tag": tag, "blocks_per_gpu": B, "kernels": {}}
+summary = {"tag": tag, "blocks_per_gpu": B, "level": level, "kernels": {}}
 if note: summary["workload"] = note
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
@@ -36,6 +37,11 @@ for k, cs in pmc.items():
     e = summary["kernels"].setdefault(k, {})
     e["pmc_per_launch"] = {c: sum(v) / len(v) for c, v in cs.items()}
     e["pmc_launches"] = {c: len(v) for c, v in cs.items()}
+    e["pmc_sum"] = {c: sum(v) for c, v in cs.items()}
+# A bench step is one ABI call per direction, but an HC call launches its kernels once per GROUP of blocks: per-step totals =
+# the sum over all launches of a pass / the steps of that pass.  k_scan (the frame body's scan) runs exactly once per step.
+steps_by_counter = summary["kernels"].get("k_scan", {}).get("pmc_launches", {})
+summary["steps_in_trace"] = summary["kernels"].get("k_scan", {}).get("calls")
 S = B * (4 << 20)
 for k in list(summary["kernels"]):
     p = summary["kernels"].get(k, {}).get("pmc_per_launch", {})
@@ -49,5 +55,12 @@ for k in list(summary["kernels"]):
         summary["kernels"][k]["l2_miss_traffic_bytes_raw"] = raw
         summary["kernels"][k]["l2_miss_traffic_bytes"] = cor
         summary["kernels"][k]["plaintext_bytes"] = S
+        nf, nw = steps_by_counter.get("FETCH_SIZE"), steps_by_counter.get("WRITE_SIZE")
+        ps = summary["kernels"][k]["pmc_sum"]
+        if nf and nw:
+            summary["kernels"][k]["l2_miss_traffic_bytes_per_step"] = (2 * ps["FETCH_SIZE"] / nf + ps["WRITE_SIZE"] / nw) * 1024
+            summary["kernels"][k]["launches_per_step"] = summary["kernels"][k]["pmc_launches"]["FETCH_SIZE"] / nf
+for k in summary["kernels"]:
+    summary["kernels"][k].pop("pmc_sum", None)
 json.dump(summary, open(os.path.join(out, "%s_summary.json" % tag), "w"), indent=1)
 print(json.dumps(summary, indent=1))

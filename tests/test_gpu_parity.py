@@ -300,7 +300,7 @@ def test_gpu_host_calls_in_many_chunks(orc, monkeypatch):
 @pytest.mark.parametrize("budget_mib,bsz,bsz_b", [(0, 4 << 20, 4 << 20), (40, 4 << 20, 4 << 20), (0, 256 << 10, 64 << 10)])
 def test_gpu_duplex_call(orc, monkeypatch, budget_mib, bsz, bsz_b):
     """plz4hip_dev_duplex_records == plz4hip_dev_encode_records of one batch + plz4hip_dev_decode_records of another (k_l1_duplex:
-    one parser wave and two decoder waves per workgroup): the records are the oracle's, the decoded blocks the other batch's
+    one parser wave and one decoder wave per workgroup by default): the records are the oracle's, the decoded blocks the other batch's
     plaintext with every status OK -- a damaged record reports as it does in the plain call -- also when the encode side runs in
     groups (the decode rides in the first one) and when either side is empty."""
     import torch
@@ -361,6 +361,48 @@ def test_gpu_duplex_call(orc, monkeypatch, budget_mib, bsz, bsz_b):
                          d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz_b, True, d_out.data_ptr(), bsz_b, bsz_b, d_res.data_ptr(), d_st.data_ptr(), s)
     torch.cuda.synchronize()
     check_decode()
+    e.close()
+
+
+def test_gpu_duplex_call_on_a_chip_full_of_blocks(orc):
+    """k_l1_duplex at the size the bench runs it in kind: 320 x 4 MiB blocks each way -- more than one block per CU, ten-wave
+    occupancy on part of the chip, persistent waves taking several blocks each -- with every record compared with the oracle's
+    (blk.CompressToBlk, blk/blk.go:69-109) and every decoded block with its plaintext.  The small duplex test runs 6-9 blocks."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    from plz4_amd._native import Engine
+    e = Engine(0)
+    bsz = 4 << 20
+    nb = 320
+    pool = synth.make("T", 16 * bsz, bsz)
+    pool[5 * bsz:6 * bsz] = synth.make("R", bsz, bsz)                       # one stored block per 16
+    pool[9 * bsz:9 * bsz + (bsz >> 1)] = 0                                  # one with a 2 MiB run (long matches, 0xFF length bytes)
+    dev = torch.device("cuda:0")
+    d_pool = torch.from_numpy(pool).to(dev)
+    d_src = torch.empty(nb * bsz, dtype=torch.uint8, device=dev)
+    for r in range(nb // 16):
+        d_src[r * 16 * bsz:(r + 1) * 16 * bsz] = torch.roll(d_pool, -((r * 1000003) % pool.size)) if r else d_pool
+    src = d_src.cpu().numpy()
+    with ThreadPoolExecutor(8) as ex:                                         # (the oracle releases the GIL inside ctypes calls)
+        want = list(ex.map(lambda i: orc.block_record(src[i * bsz:(i + 1) * bsz], bsz, True), range(nb)))
+    stride = e.stage_stride(bsz)
+    d_stage = torch.zeros(nb * stride, dtype=torch.uint8, device=dev)
+    d_len = torch.zeros(nb, dtype=torch.int32, device=dev)
+    off = np.zeros(nb + 1, dtype=np.int64); off[1:] = np.cumsum([w.size for w in want])
+    d_body = torch.from_numpy(np.concatenate(want)).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    d_out = torch.zeros(nb * bsz, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(nb, dtype=torch.int32, device=dev)
+    d_st = torch.full((nb,), -9, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    e.dev_duplex_records(d_src.data_ptr(), nb * bsz, bsz, True, d_stage.data_ptr(), d_len.data_ptr(),
+                         d_body.data_ptr(), d_off.data_ptr(), nb, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+    torch.cuda.synchronize()
+    lens = d_len.cpu().numpy(); stage = d_stage.cpu().numpy()
+    for i, w in enumerate(want):
+        assert int(lens[i]) == w.size and np.array_equal(stage[i * stride:i * stride + w.size], w), i
+    assert int(d_st.abs().sum().item()) == 0 and int(d_res.to(torch.int64).sum().item()) == nb * bsz
+    assert torch.equal(d_out, d_src)
     e.close()
 
 
@@ -440,6 +482,44 @@ def test_gpu_dev_compress_levels_and_trim(ref, orc):
     e.trim()
     recs2 = e.encode_records(srcs, 1 << 19, True)
     assert all(np.array_equal(a, b) for a, b in zip(recs, recs2))
+    e.close()
+
+
+@pytest.mark.gpu
+def test_gpu_dev_compress_on_two_streams_of_one_ctx(ref, orc):
+    """Two plz4hip_dev_compress jobs with different block counts and lengths enqueued back to back on two streams of one ctx
+    (include/plz4hip.h documents that as supported): each job's kernels must see its own sanitised lengths -- the ctx-wide copy
+    is ordered across streams like the workspaces."""
+    import torch
+    from plz4_amd._native import Engine
+    e = Engine(0)
+    dev = torch.device("cuda:0")
+    stride = 1 << 19
+    jobs = []
+    for j, (cnt, n) in enumerate(((24, 300000), (7, 70001))):
+        srcs = [synth.text(n - 13 * i, seed=20 + 7 * j + i) for i in range(cnt)]
+        d_src = torch.zeros(cnt * stride, dtype=torch.uint8, device=dev)
+        for i, s in enumerate(srcs):
+            d_src[i * stride:i * stride + s.size] = torch.from_numpy(s).to(dev)
+        jobs.append({"srcs": srcs, "src": d_src, "len": torch.tensor([s.size for s in srcs], dtype=torch.int32, device=dev),
+                     "cap": torch.full((cnt,), orc.bound(n), dtype=torch.int32, device=dev), "n": n, "stream": torch.cuda.Stream(device=dev)})
+    torch.cuda.synchronize()
+    for lvl in (1, 4):
+        for rep in range(3):
+            for jb in jobs:
+                jb["dst"] = torch.zeros(len(jb["srcs"]) * stride, dtype=torch.uint8, device=dev)
+                jb["res"] = torch.zeros(len(jb["srcs"]), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            for jb in (jobs if rep % 2 == 0 else jobs[::-1]):
+                e._chk(e.L.plz4hip_dev_compress(e.h, len(jb["srcs"]), jb["src"].data_ptr(), stride, jb["len"].data_ptr(), jb["dst"].data_ptr(), stride,
+                                                jb["cap"].data_ptr(), lvl, jb["n"], jb["res"].data_ptr(), jb["stream"].cuda_stream))
+            torch.cuda.synchronize()
+            for jb in jobs:
+                res = jb["res"].cpu().numpy(); out = jb["dst"].cpu().numpy()
+                for i, s in enumerate(jb["srcs"]):
+                    cap = orc.bound(jb["n"])
+                    want_n, want = (orc.compress_fast(s, cap) if lvl == 1 else ref.compress_hc(s, cap, lvl))
+                    assert int(res[i]) == want_n and np.array_equal(out[i * stride:i * stride + want_n], want[:want_n]), (lvl, rep, i)
     e.close()
 
 
