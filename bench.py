@@ -212,6 +212,25 @@ def crossover(args):
             "cpu": "reference liblz4 1.10.0 (oracle/_ref) + oracle xxh32, one block per task" if ref is not None else None}
 
 
+def memory_plan(B: int, world: int, gather_rank0: bool, duplex: bool, ratio: float, level: int = 1):
+    """GiB this bench holds on the busiest rank (rank 0) for B blocks per GPU: its own buffers, the library's level-1 workspace
+    (8 bytes per possible sequence -- a sequence takes at least 4 input bytes -- plus the chunk tables: launch_l1 in plz4hip.hip) and,
+    when the framed output is gathered, the assembled frame body and the receive pieces (plz4_amd/shard.py)."""
+    S = B * BSZ
+    C = ratio * S
+    g = 2.0**30
+    plan = {
+        "src": S / g, "out": S / g, "stage": B * (BSZ + 16) / g,
+        "frame_body": min(B * (BSZ + 8), C * 1.02 + (1 << 20)) / g * (2 if duplex else 1),
+        "l1_workspace": (B * ((BSZ // 4 + 3 + 63) // 64 * 64) * 8 + B * 1024 * 8) / g if level == 1 else 0.0,
+    }
+    if gather_rank0 and world > 1:
+        plan["gathered_frame"] = world * C / g
+        plan["recv_pieces"] = 2 * (world - 1) * (256 << 20) / g
+    plan["total"] = sum(plan.values())
+    return {k: round(v, 1) for k, v in plan.items()}
+
+
 def main():
     # Exactly one line goes to stdout: the JSON.  Libraries print to the C-level stdout as well (RCCL writes a version banner
     # when a communicator comes up), so file descriptor 1 is pointed at stderr for the whole run and the JSON is written to
@@ -234,6 +253,10 @@ def main():
                     help="level 1 only.  1 (default): a step is ONE duplex call (plz4hip_dev_duplex_records): the level-1 encode of this step's batch beside the "
                          "decode of the frame body the previous step produced (the decoder's waves share every CU with the parser's), "
                          "then scan + compact; 0: encode -> frame body -> decode of the same batch, one after the other")
+    ap.add_argument("--gather", choices=("rank0", "none"), default=os.environ.get("PLZ4_BENCH_GATHER", "rank0"),
+                    help="N > 1: rank0 (default) = the framed output is gathered to rank 0 over RCCL and interleaved into ONE frame body "
+                         "there (a single io.Writer); none = every rank keeps its frame body, block i on rank i mod N (SURVEY 8d config 3: "
+                         "'or left sharded -- report both'): no exchange at all")
     ap.add_argument("--decode-only", action="store_true",
                     help="configs[2]: the step is the decode of the (already framed, resident) records alone; blocks stay sharded "
                          "block i -> rank i mod N, the plaintext stays on the rank that decoded it")
@@ -269,6 +292,7 @@ def main():
     # PLZ4_BENCH_FORCE_GATHER=1 runs the N > 1 code path (process group, gather stream, interleave) with a single rank: a
     # dry run of everything but the peer transfers, for boxes with one GPU
     multi = world > 1 or bool(os.environ.get("PLZ4_BENCH_FORCE_GATHER"))
+    gather_rank0 = multi and args.gather == "rank0" and not args.decode_only
     if multi and world == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
@@ -279,6 +303,18 @@ def main():
     B = args.blocks
     S = B * BSZ
     t0 = time.time()
+    if rank == 0:
+        free0, total0 = torch.cuda.mem_get_info(dev)
+        dup0 = bool(args.duplex) and args.level == 1 and not args.decode_only
+        plan = memory_plan(B, world, gather_rank0, dup0, 0.40, args.level)
+        log("rank 0 memory plan, GiB (%d rank(s), gather %s): %s; device %.1f GiB, free %.1f GiB" %
+            (world, args.gather if multi else "-", plan, total0 / 2**30, free0 / 2**30))
+        if world == 1 and multi:                                               # the dry run also says what rank 0 of a full node would hold
+            log("rank 0 memory plan, GiB, for 8 ranks with the gather: %s" % memory_plan(B, 8, True, dup0, 0.40, args.level))
+        # a fifth of the card stays free for the allocator and for whatever else lives there: a plan that does not leave it is
+        # refused here rather than found out in the middle of a timed step (the level-1 workspace falling back to groups)
+        assert plan["total"] <= 0.8 * total0 / 2**30 or os.environ.get("PLZ4_BENCH_NO_HEADROOM_CHECK"), \
+            "rank 0 would hold %.1f GiB of %.1f: less than 20 %% headroom (fewer --blocks, or --gather none)" % (plan["total"], total0 / 2**30)
     pool = synth.make(args.kind, POOL_BLOCKS * BSZ, BSZ)
     d_pool = torch.from_numpy(pool).to(dev)
     d_src = torch.empty(S, dtype=torch.uint8, device=dev)
@@ -306,7 +342,9 @@ def main():
             "stage": torch.empty(nb * stride, dtype=torch.uint8, device=dev),
             "len": torch.zeros(nb, dtype=torch.int32, device=dev),
             "off": torch.zeros(nb + 1, dtype=torch.int64, device=dev),
-            "body": torch.empty(nb * (BSZ + 8), dtype=torch.uint8, device=dev),
+            # the frame body is sized for the data at hand, not for the worst case (24 GiB per 6144 blocks): 0.55 of the plaintext
+            # to begin with (T text stores 0.38), the worst case only if the parity gate's compaction reports that it did not fit
+            "body": torch.empty(min(nb * (BSZ + 8), int(nb * BSZ * float(os.environ.get("PLZ4_BENCH_BODY_FRAC", "0.55"))) + (1 << 20)), dtype=torch.uint8, device=dev),
             "res": torch.zeros(nb, dtype=torch.int32, device=dev),
             "st": torch.zeros(nb, dtype=torch.int32, device=dev),
         })
@@ -321,7 +359,7 @@ def main():
     s_dec = torch.cuda.Stream(device=dev) if NP > 1 else s_enc
     # N > 1: the framed-output gather (RCCL send/recv + the interleave on rank 0) runs on its own stream, next to the decode
     # of the same records -- the decoder reads the local body and does not wait for the exchange
-    s_gat = torch.cuda.Stream(device=dev) if multi else None
+    s_gat = torch.cuda.Stream(device=dev) if gather_rank0 else None
     log("rank %d: %d blocks (%.1f GiB) in %d part(s) ready in %.1fs" % (rank, B, S / 2**30, NP, time.time() - t0))
 
     gather = {}
@@ -366,7 +404,7 @@ def main():
         pt["cur"] = cur; pt["body"] = pt["bodies"][cur]; pt["off"] = pt["offs"][cur]
         packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
         packed.record(s_enc)
-        if multi:
+        if gather_rank0:
             s_gat.wait_event(packed)
             with torch.cuda.stream(s_gat):
                 frame_gather(pt)
@@ -394,7 +432,7 @@ def main():
                                     pt["body"].data_ptr(), pt["body"].numel(), s_enc.cuda_stream)
             packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
             packed.record(s_enc)
-            if multi:
+            if gather_rank0:
                 s_gat.wait_event(packed)
                 with torch.cuda.stream(s_gat):                 # collectives and the interleave kernels take the current stream
                     frame_gather(pt)
@@ -418,6 +456,14 @@ def main():
     torch.cuda.synchronize()
     step()
     torch.cuda.synchronize()
+    for pt in parts:
+        if int(pt["off"][-1].item()) > pt["body"].numel():                   # (compaction skips what does not fit and says so here)
+            log("rank %d: frame body of %.1f GiB too small for this data, taking the worst case" % (rank, pt["body"].numel() / 2**30))
+            pt["body"] = None
+            pt["body"] = torch.empty(pt["nb"] * (BSZ + 8), dtype=torch.uint8, device=dev)
+            if duplex: pt["bodies"][0] = pt["body"]
+            d_out.zero_(); torch.cuda.synchronize(); step(); torch.cuda.synchronize()
+            break
     assert sum(int(pt["st"].abs().sum().item()) for pt in parts) == 0, "decode status != OK"
     assert sum(int(pt["res"].to(torch.int64).sum().item()) for pt in parts) == S, "decoded size mismatch"
     assert torch.equal(d_out, d_src), "round trip mismatch"
@@ -430,6 +476,16 @@ def main():
         log("parity gate ok: round trip exact, every block status OK, stored/plain ratio %.4f "
             "(two records are compared with the reference encoder in the cpu_baseline leg)" % (C_bytes / S))
 
+    for pt in parts:                                                         # the gate has told how large a body is: keep that + 2 %
+        c_pt = int(pt["off"][-1].item())
+        want = min(pt["body"].numel(), int(c_pt * 1.02) + (1 << 20))
+        if want < pt["body"].numel():
+            nb_ = torch.empty(want, dtype=torch.uint8, device=dev)
+            nb_[:c_pt] = pt["body"][:c_pt]
+            pt["body"] = nb_
+            if duplex: pt["bodies"][0] = nb_
+    d_body = parts[0]["body"]
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
     if duplex:
         d_out.zero_()                                                        # what the timed steps decode is checked again below
         # the same input every step, so the same body: the second one is that size + 2 % (compact skips what would not fit and
@@ -581,6 +637,9 @@ def main():
             t = committed_traffic(kern, B, args.level) if key in out else None
             if t:
                 out[key]["traffic"] = t["bytes"]; out[key]["traffic_source"] = t["source"]; out[key]["traffic_per"] = t["per"]
+        free1, total1 = torch.cuda.mem_get_info(dev)
+        out["config"]["gather"] = (args.gather if multi else None)
+        out["memory_gib"] = {"plan": plan, "held_at_end": round((total1 - free1) / 2**30, 1), "device": round(total1 / 2**30, 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool, level=args.level, check=check_pairs)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

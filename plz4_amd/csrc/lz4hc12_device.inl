@@ -67,9 +67,11 @@ DEV uint32_t hc12_hash(uint32_t v) { return (v * 2654435761u) >> 17; }
 // list cursor per hash: 2 x 64 KiB) fit.  Per lane one atomic max (commits the position, returns the previous holder) and one
 // atomic add (takes the list slot); same-slot lanes are expected to resolve in ascending lane order, any other order is
 // detected and put right in place.  chain[0, nPad) is written (nPad % 64 == 0), rank / list for positions below n - 3.
+// [skipLo, skipHi): positions that are never inserted (an external segment's last three, lz4hc.c:1660-1678: LZ4HC_setExternalDict
+// references the segment up to its end - 3 and resumes at the prefix); they get no list entry and nobody's chain leads to them.
 DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const uint32_t* __restrict__ offsets,
                           uint16_t* __restrict__ chain, uint32_t* __restrict__ rank, uint32_t* __restrict__ list, const int nPad,
-                          uint32_t* lastT, uint32_t* curT)
+                          uint32_t* lastT, uint32_t* curT, const int skipLo = 0, const int skipHi = 0)
 {
     const int nIns = n >= 4 ? n - 3 : 0;                       // positions with 4 bytes to hash
     for (int half = 0; half < 2; ++half) {
@@ -83,7 +85,7 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
             LANES({
                 const int p = base + LANE;
                 act[I_] = 0; h[I_] = 0; prev[I_] = 0; slot[I_] = 0;
-                if (p < nIns) {
+                if (p < nIns && !(p >= skipLo && p < skipHi)) {
                     const uint32_t hv = hc12_hash(w[I_]);
                     if ((int)(hv >> 14) == half) {
                         act[I_] = 1; h[I_] = hv & 16383u;
@@ -121,7 +123,7 @@ DEV void hc12_build_lists(const uint8_t* __restrict__ src, const int n, const ui
                     chain[p] = (uint16_t)d;
                     rank[p] = slot[I_];
                     list[slot[I_]] = (uint32_t)p | (prev[I_] ? 0u : kHc12First);
-                } else if (p >= nIns && half == 0) chain[p] = 0;
+                } else if ((p >= nIns || (p >= skipLo && p < skipHi)) && half == 0) chain[p] = 0;
             })
         };
         // Sixteen steps' words are in flight: loads and stores of a wave complete in order, so the wait for a word is also a wait

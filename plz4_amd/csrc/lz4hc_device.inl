@@ -92,7 +92,12 @@ DEV int hc_count(const uint8_t* a, const uint8_t* b, const uint8_t* limit)
 // LZ4HC_Insert (lz4hc.c:781-802): chain every position below `pos`
 DEV uint32_t hc_link(const HcState& s, uint32_t idx)       // chain table entry of index idx (lz4hc.c:228 DELTANEXTU16)
 {
-    if (s.w.pre) { const uint32_t d = s.w.pre[idx - kHcBase]; return d ? d : 65535u; }
+    if (s.w.pre) {
+        // (an external segment's last three positions are never inserted, lz4hc.c:1660-1678: their entries of the freshly zeroed
+        // table -- LZ4_loadDictHC starts from LZ4_initStreamHC, :1626-1653 -- stay 0; the chain swap may read them, :964-987)
+        if (s.d.mode == kHcExt && (kHcBase + (uint32_t)s.pfx - 1u) - idx < 3u) return 0u;
+        const uint32_t d = s.w.pre[idx - kHcBase]; return d ? d : 65535u;
+    }
     return s.w.chain[idx & 0xFFFFu];
 }
 DEV void hc_insert(HcState& s, int pos)
@@ -159,9 +164,17 @@ DEV bool hc_protect(uint32_t prefixIdx, uint32_t mi) { return (uint32_t)((prefix
 // chain links are evaluated together, and the first lane where something happens (the tests pass: the match is measured; the
 // link is 1: pattern analysis, level 9) is handled exactly as the reference handles that candidate; the lanes below it were
 // candidates that change nothing.  One dependent memory round trip per ROUND instead of one per candidate.
+// kD: the block has an external segment of s.pfx bytes in front of it (kHcExt) whose positions are in the lists as well -- all but
+// its last three, which the reference never inserts.  What the reference does differently for a candidate inside the segment is
+// kept: no 2-byte pre-check (:940-960), the look-back may go down to the segment's first byte while a candidate in the block stops
+// at the block's (:933 vs :953), and the pattern analysis never lands on the segment's last three positions (LZ4HC_protectDictEnd,
+// :876-879, :1003-1060).
+template <bool kD = false>
 DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit, int longest, int nbSearches, bool patternAnalysis, bool chainSwap)
 {
     const uint8_t* const src = s.src;
+    const int pfxPos = kD ? s.pfx : 0;
+    const uint32_t prefixIdx = kHcBase + (uint32_t)pfxPos;
     const uint8_t* const ip = src + pos;
     const uint8_t* const iLow = src + lowLimit;
     const uint8_t* const iHigh = src + highLimit;
@@ -220,7 +233,9 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                         const uint32_t m16 = ld16u(mp - lookBack + L - 1);
                         if (useFw) { const uint64_t x = ld64u(mp + 4) ^ ip64; fw[I_] = x ? (ctz64(x) >> 3) : 8; }
                         pfx[I_] = ld32u(mp) == pattern;
-                        pass[I_] = pfx[I_] && m16 == ip16 && !(fw[I_] < 8 && 4 + fw[I_] + lookBack < L);
+                        // (inside the segment: no 2-byte pre-check, but -- the chain swap can lead there -- not its last three positions, :943)
+                        const int cq = (int)q[I_] - cp;
+                        pass[I_] = pfx[I_] && ((kD && cq < pfxPos) ? cq <= pfxPos - 4 : m16 == ip16) && !(fw[I_] < 8 && 4 + fw[I_] + lookBack < L);
                         pat[I_] = patternAnalysis && dn[I_] == 1u && cp == 0;
                     }
                 })
@@ -239,7 +254,7 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                     LANES({
                         pass[I_] = 0;
                         if (LANE >= st && LANE < en && pfx[I_] && !(fw[I_] < 8 && 4 + fw[I_] + lookBack < L))
-                            pass[I_] = ld16u(src + q[I_] - cp - lookBack + L - 1) == ip16;
+                            pass[I_] = (kD && (int)q[I_] - cp < pfxPos) ? ((int)q[I_] - cp <= pfxPos - 4) : (ld16u(src + q[I_] - cp - lookBack + L - 1) == ip16);
                     })
                     passFor = longest;
                 }
@@ -259,8 +274,8 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                 mi = RL(q, k) - chainPos + kHcBase;
                 const uint32_t dnk = RL(dn, k);
                 const uint8_t* const mp = src + (mi - kHcBase);
-                if (RL(pass, k)) {                                                    // :933-939
-                    const int back = lookBack ? hc_count_back(ip, mp, iLow, src) : 0;
+                if (RL(pass, k)) {                                                    // :933-939 / :940-960
+                    const int back = lookBack ? hc_count_back(ip, mp, iLow, (kD && mi >= prefixIdx) ? src + pfxPos : src) : 0;
                     const int fwk = RL(fw, k);
                     int mlen = fwk < 8 ? kMinMatch + fwk
                              : fwk == 8 ? kMinMatch + 8 + hc_count(ip + kMinMatch + 8, mp + kMinMatch + 8, iHigh)
@@ -295,7 +310,7 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                             srcPatternLength = hc_count_pattern(ip + 4, iHigh, pattern) + 4;
                         } else repeat = 1;
                     }
-                    if (repeat == 2 && mci >= lowest) {
+                    if (repeat == 2 && mci >= lowest && (!kD || hc_protect(prefixIdx, mci))) {
                         const uint8_t* const mq = src + (mci - kHcBase);
                         if (UNI(ld32u(mq)) == pattern) {
                             const size_t fwd = hc_count_pattern(mq + 4, iHigh, pattern) + 4;
@@ -305,6 +320,10 @@ DEV HcMatch hc_find_wider_lists(HcState& s, int pos, int lowLimit, int highLimit
                             const size_t seg = back + fwd;
                             if (seg >= srcPatternLength && fwd <= srcPatternLength) {
                                 mi = mci + (uint32_t)fwd - (uint32_t)srcPatternLength;     // :1027-1036: looked at next
+                                if (kD && !hc_protect(prefixIdx, mi)) mi = prefixIdx;
+                                cursor = (int)UNI(s.w.rank[mi - kHcBase]);
+                            } else if (kD && !hc_protect(prefixIdx, mci - (uint32_t)back)) {
+                                mi = prefixIdx;                                            // :1040-1042
                                 cursor = (int)UNI(s.w.rank[mi - kHcBase]);
                             } else {
                                 mi = mci - (uint32_t)back;                                 // :1038-1058
@@ -350,7 +369,9 @@ DEV HcMatch hc_find_wider(HcState& s, int pos, int lowLimit, int highLimit, int 
                           bool patternAnalysis, bool chainSwap)
 {
     if (!kD && s.w.list && nbSearches >= 8)                     // levels 4..12 on an independent block: 63 candidates per round
-        return hc_find_wider_lists(s, pos, lowLimit, highLimit, longest, nbSearches, patternAnalysis, chainSwap);
+        return hc_find_wider_lists<false>(s, pos, lowLimit, highLimit, longest, nbSearches, patternAnalysis, chainSwap);
+    if (kD && s.w.list && s.d.mode == kHcExt)                   // ... and behind an external segment whose positions are in the lists too
+        return hc_find_wider_lists<true>(s, pos, lowLimit, highLimit, longest, nbSearches, patternAnalysis, chainSwap);
     const uint8_t* const src = s.src;
     const uint8_t* const ip = src + pos;
     const uint8_t* const iLow = src + lowLimit;

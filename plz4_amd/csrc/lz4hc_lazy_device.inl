@@ -53,10 +53,11 @@ enum : int { kLzFirst = 0, kLzSecond = 1, kLzThird = 2 };
 // Sequence records of one block, 64 at a time (one coalesced store)
 struct SeqSink {
     uint64_t* seq; int n;
+    int bias = 0;                 // (a walk behind an external segment counts positions from the segment's first byte: records count from the block's)
     LV(uint64_t, buf);
     DEVM void put(int pos, int ml, int off)
     {
-        const uint64_t r = seq_pack((uint32_t)pos, (uint32_t)(ml - kMinMatch), (uint32_t)off);
+        const uint64_t r = seq_pack((uint32_t)(pos - bias), (uint32_t)(ml - kMinMatch), (uint32_t)off);
         const int slot = n & 63;
         LANES({ if (LANE == slot) buf[I_] = r; })
         ++n;
@@ -79,6 +80,11 @@ struct LzFound { int pos, len, off, back; };          // pos < 0: nothing
 // one round of at most 64 candidates: those ciBase.. below the position in its list; *more: every lane had a candidate (the chain
 // goes on below them).  len = the largest total of the round (0: none), first candidate first.
 // *link1: a candidate of the round has a chain link of 1 (where level 9's pattern analysis would step in, :989).
+// kD: an external segment of s.pfx bytes lies in front of the block and its positions (all but its last three) are in the lists:
+// a candidate in the block is not extended backwards into the segment (lz4hc.c:933: LZ4HC_countBack down to prefixPtr), one in the
+// segment down to the segment's first byte (:953); the segment's candidates have no 2-byte pre-check (:940-960), which changes
+// nothing here: every candidate is counted exactly.
+template <bool kD = false>
 DEV LzFound hc_find_round(const HcState& s, const int pos, const int low, const int highLimit, const int nb,
                           const bool multi, const int mflimit, const int ciBase, bool* more, bool* link1)
 {
@@ -113,7 +119,7 @@ DEV LzFound hc_find_round(const HcState& s, const int pos, const int low, const 
             const uint8_t* const ipp = src + p[I_];
             const uint8_t* const mp = src + q[I_];
             if (ld32u(mp) == ld32u(ipp)) {                                                          // :930
-                const int back = lookBack ? hc_count_back(ipp, mp, src + low, src) : 0;              // :933 (<= 0)
+                const int back = lookBack ? hc_count_back(ipp, mp, src + low, (kD && q[I_] >= s.pfx) ? src + s.pfx : src) : 0;   // :933 / :953 (<= 0)
                 total = kMinMatch + hc_count(ipp + kMinMatch, mp + kMinMatch, iHigh) - back;
                 bk[I_] = back;
             }
@@ -139,14 +145,15 @@ DEV LzFound hc_find_round(const HcState& s, const int pos, const int low, const 
 }
 // pa: level 9 (pattern analysis on).  Its walk is this one as long as no candidate it looks at has a link of 1; when one has,
 // pos = -2 comes back and the caller asks hc_find_wider_lists, which plays the pattern analysis.
+template <bool kD = false>
 DEV LzFound hc_find_few(const HcState& s, const int pos, const int low, const int highLimit, const int longest, const int nb,
                         const bool multi, const int mflimit, const bool pa = false)
 {
     bool more = false, l1 = false, any1 = false;
-    LzFound best = hc_find_round(s, pos, low, highLimit, nb < 64 ? nb : 64, multi, mflimit, 0, &more, pa ? &l1 : nullptr);
+    LzFound best = hc_find_round<kD>(s, pos, low, highLimit, nb < 64 ? nb : 64, multi, mflimit, 0, &more, pa ? &l1 : nullptr);
     any1 = l1;
     for (int base = 64; base < nb && more && !any1; base += 64) {           // (128 / 256 attempts: more rounds, for the one position)
-        const LzFound f = hc_find_round(s, pos, low, highLimit, nb - base < 64 ? nb - base : 64, false, mflimit, base, &more, pa ? &l1 : nullptr);
+        const LzFound f = hc_find_round<kD>(s, pos, low, highLimit, nb - base < 64 ? nb - base : 64, false, mflimit, base, &more, pa ? &l1 : nullptr);
         any1 |= l1;
         if (f.len > best.len) best = f;                                     // a later candidate replaces only when longer (:934)
     }
@@ -164,26 +171,34 @@ struct LzNoHook { DEVM bool operator()(int, int, int) const { return false; } };
 // to seq[0..).
 // kPa: level 9 (pattern analysis).  A template parameter so that the code of levels 3..8 does not carry the general finder (three
 // inlined copies of it cost levels 3..6 a quarter of their speed: instruction cache).
-template <bool kPa, class Hook>
-DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
-                        const int ipStart, const int anchorStart, const int ipStop, Hook& hook)
+// kD: the block (`blk`, n bytes) has an external segment of pfx bytes right in front of it in memory (a linked block after
+// LZ4_loadDictHC(previous tail), or a block > 4 KiB under an attached dictionary: lz4hc.c:1438-1461, :1626-1720) and w's chain and
+// lists were built over segment + block (positions from the segment's first byte; the segment's last three positions left out,
+// :1660-1678).  The interface stays in positions of the BLOCK -- ipStart / anchorStart / ipStop, the hook's arguments, the records,
+// the LzRun that comes back -- so segments, stitching and the emit stage do not know.
+template <bool kPa, bool kD, class Hook>
+DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ blk, const int pfxArg, const int n, const int level, HcWork w, uint64_t* seq,
+                        const int ipStart, const int anchorStart, const int ipStopRel, Hook& hook)
 {
     const int  maxNb = 1 << (level - 1);
     const bool pa = kPa;
-    HcState s; s.src = src; s.pfx = 0; s.w = w; s.nextToUpdate = 0; s.d.mode = kHcNone; s.d.len = 0; s.d.bytes = nullptr; s.d.hash = nullptr; s.d.chain = nullptr;
-    const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
+    const int  pfx = kD ? pfxArg : 0;
+    const uint8_t* const src = blk - pfx;
+    HcState s; s.src = src; s.pfx = pfx; s.w = w; s.nextToUpdate = 0; s.d.mode = kD ? kHcExt : kHcNone; s.d.len = pfx; s.d.bytes = nullptr; s.d.hash = nullptr; s.d.chain = nullptr;
+    const int mflimit = pfx + n - kMfLimit, matchlimit = pfx + n - kLastLiterals;
     const int kOptimalMl = 15 - 1 + kMinMatch;                                                   // OPTIMAL_ML, lz4hc.c:75
-    SeqSink out; out.seq = seq; out.n = 0;
+    SeqSink out; out.seq = seq; out.n = 0; out.bias = pfx;
     LANES({ out.buf[I_] = 0; })
-    int ip = ipStart, anchor = anchorStart;
+    int ip = pfx + ipStart, anchor = pfx + anchorStart;
+    const int ipStop = pfx + ipStopRel;
     LzRun run; run.cnt = 0; run.endIp = ipStart; run.finished = 1; run.anchor = anchorStart;
     if (n < kMinLength) return run;                                                              // :1155
 
     // one candidate per lane (hc_find_few), first searches in groups of 64 / attempts; level 9 falls back to the general finder
     // for the searches that meet a link of 1
     auto wider = [&](int pos, int low, int longest) {
-        const LzFound f = hc_find_few(s, pos, low, matchlimit, longest, maxNb, false, mflimit, pa);
-        if (kPa && f.pos == -2) return hc_find_wider_lists(s, pos, low, matchlimit, longest, maxNb, pa, false);
+        const LzFound f = hc_find_few<kD>(s, pos, low, matchlimit, longest, maxNb, false, mflimit, pa);
+        if (kPa && f.pos == -2) return hc_find_wider_lists<kD>(s, pos, low, matchlimit, longest, maxNb, pa, false);
         HcMatch m; m.len = f.len; m.off = f.off; m.back = f.back;
         return m;
     };
@@ -197,9 +212,9 @@ DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int 
             bool found = false;
             if (ip >= ipStop && ip <= mflimit) { run.finished = 0; break; }
             while (ip <= mflimit) {
-                const LzFound f = hc_find_few(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, true, mflimit, pa);
+                const LzFound f = hc_find_few<kD>(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, true, mflimit, pa);
                 if (kPa && f.pos == -2) {                            // (level 9, a link of 1 among ip's candidates)
-                    m1 = hc_find_wider_lists(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, pa, false);
+                    m1 = hc_find_wider_lists<kD>(s, ip, ip, matchlimit, kMinMatch - 1, maxNb, pa, false);
                     if (m1.len < kMinMatch) { ip++; continue; }
                 } else {
                     if (f.pos < 0) { ip += maxNb < 64 ? 64 / maxNb : 1; continue; }
@@ -209,7 +224,7 @@ DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int 
                 break;
             }
             if (!found) break;
-            if (hook(ip, 0, out.n)) { run.finished = 0; break; }
+            if (hook(ip - pfx, 0, out.n)) { run.finished = 0; break; }
             start0 = ip; m0 = m1;
             st = kLzSecond;
         }
@@ -285,7 +300,7 @@ DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int 
         start2 = start3; m2 = m3;
     }
     out.finish();
-    run.cnt = out.n; run.endIp = ip; run.anchor = anchor;
+    run.cnt = out.n; run.endIp = ip - pfx; run.anchor = anchor - pfx;
     return run;
 }
 
@@ -295,26 +310,33 @@ DEV LzRun hc_lazy_run_t(const uint8_t* __restrict__ src, const int n, const int 
 // cannot be computed ahead like level 12's), its sequences are records, and it is walked in segments like the lazy levels.  One
 // difference: at the top of its loop (:1863) this parser's state is (ip, anchor) -- the literal run in front of a window enters
 // its prices (:1885-1894) -- so two walks have met when they find their next first match at the same position WITH the same anchor.
-template <class Hook>
-DEV LzRun hc_opt_run(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
-                     const int ipStart, const int anchorStart, const int ipStop, Hook& hook)
+// kD: behind an external segment of pfx bytes (see hc_lazy_run_t).  There level 12 takes this route as well (its own design,
+// lz4hc12_device.inl, computes every position's search up front on the independent block): 16384 attempts, sufficient_len 4095
+// and the full update (:1406, :1929-1936: the skip test looks four positions ahead and every search starts from MINMATCH - 1).
+template <bool kD, class Hook>
+DEV LzRun hc_opt_run(const uint8_t* __restrict__ blk, const int pfxArg, const int n, const int level, HcWork w, uint64_t* seq,
+                     const int ipStart, const int anchorStart, const int ipStopRel, Hook& hook)
 {
-    const int nbSearches = level == 11 ? 512 : 96;                                               // table :92-106
-    const int sufficient = level == 11 ? 128 : 64;
+    const int  nbSearches = level >= 12 ? 16384 : (level == 11 ? 512 : 96);                      // table :92-106
+    const int  sufficient = level >= 12 ? kHcOptNum - 1 : (level == 11 ? 128 : 64);              // (:1860: capped to LZ4_OPT_NUM - 1)
+    const bool fullUpdate = level >= 12;
     HcOpt* const opt = w.opt;
-    HcState s; s.src = src; s.pfx = 0; s.w = w; s.nextToUpdate = 0; s.d.mode = kHcNone; s.d.len = 0; s.d.bytes = nullptr; s.d.hash = nullptr; s.d.chain = nullptr;
-    const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
-    SeqSink out; out.seq = seq; out.n = 0;
+    const int pfx = kD ? pfxArg : 0;
+    const uint8_t* const src = blk - pfx;
+    HcState s; s.src = src; s.pfx = pfx; s.w = w; s.nextToUpdate = 0; s.d.mode = kD ? kHcExt : kHcNone; s.d.len = pfx; s.d.bytes = nullptr; s.d.hash = nullptr; s.d.chain = nullptr;
+    const int mflimit = pfx + n - kMfLimit, matchlimit = pfx + n - kLastLiterals;
+    SeqSink out; out.seq = seq; out.n = 0; out.bias = pfx;
     LANES({ out.buf[I_] = 0; })
-    int ip = ipStart, anchor = anchorStart;
+    int ip = pfx + ipStart, anchor = pfx + anchorStart;
+    const int ipStop = pfx + ipStopRel;
     LzRun run; run.finished = 1;
     while (ip <= mflimit) {                                                                      // :1863
         if (ip >= ipStop) { run.finished = 0; break; }
         const int llen = ip - anchor;
         int bestMl = 0, bestOff = 0, cur, last = 0;
-        const HcMatch first = hc_find_longer<false>(s, ip, matchlimit, kMinMatch - 1, nbSearches);
+        const HcMatch first = hc_find_longer<kD>(s, ip, matchlimit, kMinMatch - 1, nbSearches);
         if (first.len == 0) { ip++; continue; }
-        if (hook(ip, anchor, out.n)) { run.finished = 0; break; }
+        if (hook(ip - pfx, anchor - pfx, out.n)) { run.finished = 0; break; }
         if (first.len > sufficient) {                                                            // :1871-1882
             out.put(ip, first.len, first.off);
             ip += first.len; anchor = ip;
@@ -337,8 +359,9 @@ DEV LzRun hc_opt_run(const uint8_t* __restrict__ src, const int n, const int lev
         for (cur = 1; cur < last; ++cur) {                                                       // :1922-2019
             const int curPos = ip + cur;
             if (curPos > mflimit) break;
-            if (opt[cur + 1].price <= opt[cur].price) continue;                                  // :1932-1934 (no full update)
-            const HcMatch nm = hc_find_longer<false>(s, curPos, matchlimit, last - cur, nbSearches);
+            if (fullUpdate) { if (opt[cur + 1].price <= opt[cur].price && opt[cur + kMinMatch].price < opt[cur].price + 3) continue; }   // :1929-1931
+            else if (opt[cur + 1].price <= opt[cur].price) continue;                             // :1932-1934
+            const HcMatch nm = hc_find_longer<kD>(s, curPos, matchlimit, fullUpdate ? kMinMatch - 1 : last - cur, nbSearches);
             if (!nm.len) continue;
             if (nm.len > sufficient || nm.len + cur >= kHcOptNum) {                              // :1948-1956
                 bestMl = nm.len; bestOff = nm.off; last = cur + 1; direct = true;
@@ -403,17 +426,18 @@ DEV LzRun hc_opt_run(const uint8_t* __restrict__ src, const int n, const int lev
         }
     }
     out.finish();
-    run.cnt = out.n; run.endIp = ip; run.anchor = anchor;
+    run.cnt = out.n; run.endIp = ip - pfx; run.anchor = anchor - pfx;
     return run;
 }
 
-template <class Hook>
-DEV LzRun hc_lazy_run(const uint8_t* __restrict__ src, const int n, const int level, HcWork w, uint64_t* seq,
+// pfx < 0: an independent block without a segment (the instantiations the frame path's blocks have always run); pfx >= 0: kD
+template <bool kD, class Hook>
+DEV LzRun hc_lazy_run(const uint8_t* __restrict__ blk, const int pfx, const int n, const int level, HcWork w, uint64_t* seq,
                       const int ipStart, const int anchorStart, const int ipStop, Hook& hook)
 {
-    if (level >= 10) return hc_opt_run(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook);
-    if ((1 << (level - 1)) > 128) return hc_lazy_run_t<true>(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook);      // pattern analysis above 128 attempts
-    return hc_lazy_run_t<false>(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook);
+    if (level >= 10) return hc_opt_run<kD>(blk, pfx, n, level, w, seq, ipStart, anchorStart, ipStop, hook);
+    if ((1 << (level - 1)) > 128) return hc_lazy_run_t<true, kD>(blk, pfx, n, level, w, seq, ipStart, anchorStart, ipStop, hook);      // pattern analysis above 128 attempts
+    return hc_lazy_run_t<false, kD>(blk, pfx, n, level, w, seq, ipStart, anchorStart, ipStop, hook);
 }
 
 // ---- segments.  Layout of a block's workspace (entries of 8 bytes): rec[j * segCap ..): the records of segment j;
@@ -454,10 +478,11 @@ DEV void lz_segment(Run& run, int n, int segs, int j, uint64_t* rec, LzSegMeta* 
     const int ns = note.n;
     LANES({ if (LANE == 0) { meta[j].seg = r; meta[j].nStarts = ns; meta[j].skip = 0; meta[j].bridge.cnt = 0; } })
 }
+template <bool kD = false>
 DEV void hc_lazy_segment(const uint8_t* __restrict__ src, int n, int level, HcWork w, int segs, int j,
-                         uint64_t* rec, LzSegMeta* meta, uint64_t* starts)
+                         uint64_t* rec, LzSegMeta* meta, uint64_t* starts, int pfx = 0)
 {
-    auto run = [&](uint64_t* seq, int ipStart, int anchorStart, int ipStop, auto& hook) { return hc_lazy_run(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook); };
+    auto run = [&](uint64_t* seq, int ipStart, int anchorStart, int ipStop, auto& hook) { return hc_lazy_run<kD>(src, pfx, n, level, w, seq, ipStart, anchorStart, ipStop, hook); };
     lz_segment(run, n, segs, j, rec, meta, starts);
 }
 
@@ -498,10 +523,11 @@ DEV int lz_stitch(Run& run, int n, int segs, uint64_t* rec, uint64_t* bridge, Lz
     *lastAnchor = cur.anchor;
     return total;
 }
+template <bool kD = false>
 DEV int hc_lazy_stitch(const uint8_t* __restrict__ src, int n, int level, HcWork w, int segs,
-                       uint64_t* rec, uint64_t* bridge, LzSegMeta* meta, const uint64_t* starts, LzPiece* pieces, int* lastAnchor)
+                       uint64_t* rec, uint64_t* bridge, LzSegMeta* meta, const uint64_t* starts, LzPiece* pieces, int* lastAnchor, int pfx = 0)
 {
-    auto run = [&](uint64_t* seq, int ipStart, int anchorStart, int ipStop, auto& hook) { return hc_lazy_run(src, n, level, w, seq, ipStart, anchorStart, ipStop, hook); };
+    auto run = [&](uint64_t* seq, int ipStart, int anchorStart, int ipStop, auto& hook) { return hc_lazy_run<kD>(src, pfx, n, level, w, seq, ipStart, anchorStart, ipStop, hook); };
     return lz_stitch(run, n, segs, rec, bridge, meta, starts, pieces, lastAnchor);
 }
 // level 12 (lz4hc12_device.inl): its price DP over the search results F, walked in segments the same way

@@ -52,6 +52,8 @@ struct CodecArgs {
     const uint32_t* hcDictHash;                     // HC + dictionary: the dictionary context's tables for this level's strategy
     const uint16_t* hcDictChain;                    //   (clz4.NewDictCtxHC, clz4.go:122-147), built by k_hc_dict_prime
     int             hcEx;                           // HC call with a dictionary and/or linked blocks: inputs have 64 KiB of scratch in front
+    int32_t*        hcPfx;                          // such a call on the list path (k_hc_ext_prep): per block, the bytes of the external segment that
+                                                    // lies right in front of it (>= 0), or -1: a block <= 4 KiB under a dictionary context (k_encode_*_hc's)
     // level 12 in three phases (lz4hc12_device.inl): per-block chain and search results of the group [blk0, blk0 + nBlocks)
     int             blk0;
     uint16_t*       h12Chain;   int64_t h12ChainStride;      // entries per block (a multiple of 1024)
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(64) void k_encode_raw_hc(CodecArgs a)
         const int n = block_len(a, i);
         const uint8_t* s = a.src + (int64_t)i * a.srcStride;
         int r;
+        if (a.hcPfx && a.hcPfx[i] >= 0) continue;                          // (done on the list path)
         if (dictMode) r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, w, hc_dict_of(a, i, n, s, true));
         else          r = hc_compress(s, n, a.dst + (int64_t)i * a.dstStride, cap, a.level, hc_with_pre(w, a, g));
         if ((threadIdx.x & 63u) == 0) a.result[i] = r;
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
         const uint8_t* s   = a.src + (int64_t)i * a.srcStride;
         uint8_t*       rec = a.dst + (int64_t)i * a.dstStride;
         int c;                                                           // capacity == bsz (blk.go:73); indie.go:80-88
+        if (a.hcPfx && a.hcPfx[i] >= 0) continue;                          // (done on the list path)
         if (exMode) c = hc_compress(s, n, rec + 4, a.bsz, a.level, w, hc_dict_of(a, i, n, s, false));
         else        c = hc_compress(s, n, rec + 4, a.bsz, a.level, hc_with_pre(w, a, g));
         uint32_t word = (uint32_t)c & 0x7FFFFFFFu;
@@ -475,6 +479,22 @@ __global__ __launch_bounds__(64) void k_encode_rec_hc(CodecArgs a)
     }
 }
 
+// HC levels 3..12 with a dictionary and/or linked blocks on the list path (round 4): how every block of the call is primed
+// (hc_dict_of: clz4.go:181-209, :250-283), its external segment copied right in front of it, its length noted.  One wave per block.
+__global__ __launch_bounds__(64) void k_hc_ext_prep(CodecArgs a)
+{
+    for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        const int n = block_len(a, i);
+        const uint8_t* s = a.src + (int64_t)i * a.srcStride;
+        const HcDict d = hc_dict_of(a, i, n, s, a.rawMode != 0);
+        // (no segment and no context -- the first block of a linked frame without a dictionary -- is an empty segment)
+        const int pfx = d.mode == kHcCtx ? -1 : (d.mode == kHcExt ? d.len : 0);
+        if ((threadIdx.x & 63u) == 0) a.hcPfx[i] = pfx;
+    }
+}
+// the segment length of block i of an HC call (0: none), and the positions in front of the block that are never inserted
+__device__ __forceinline__ int hc_pfx_of(const CodecArgs& a, int i) { return a.hcPfx ? a.hcPfx[i] : 0; }
+
 // ---------------------------------------------------------------------------------------------- HC level 12, three phases
 // Phase 1a: how many positions every hash has, then where its run starts in the list (exclusive prefix sum).  One 16-wave
 // workgroup per block, the 32768 counters in LDS.
@@ -490,12 +510,15 @@ __global__ __launch_bounds__(1024) void k_hc12_hist(CodecArgs a)
         const int g = cur;
         if (g >= a.nBlocks) break;
         const int i = a.blk0 + g;
-        const int n = block_len(a, i);
-        const uint8_t* const src = a.src + (int64_t)i * a.srcStride;
+        const int pfx = hc_pfx_of(a, i);                                   // (an external segment in front of the block: positions count from its first byte)
+        if (pfx < 0) { __syncthreads(); continue; }
+        const int n = pfx + block_len(a, i);
+        const uint8_t* const src = a.src + (int64_t)i * a.srcStride - pfx;
         for (int h = tid; h < kHcHashEntries; h += 1024) hist[h] = 0u;
         __syncthreads();
         const int nIns = n >= 4 ? n - 3 : 0;
-        for (int p = tid; p < nIns; p += 1024) atomicAdd(&hist[hc12_hash(ld32u(src + p))], 1u);
+        const int skipLo = pfx > 3 ? pfx - 3 : 0;                           // the segment's last three positions are never inserted (lz4hc.c:1660-1678)
+        for (int p = tid; p < nIns; p += 1024) if (p < skipLo || p >= pfx) atomicAdd(&hist[hc12_hash(ld32u(src + p))], 1u);
         __syncthreads();
         uint32_t sum = 0;
         for (int k = 0; k < 32; ++k) sum += hist[tid * 32 + k];
@@ -521,12 +544,14 @@ __global__ __launch_bounds__(64) void k_hc12_chain(CodecArgs a)
     __shared__ uint32_t curT[kHcHashEntries / 2];
     for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
         const int i = a.blk0 + g;
-        const int n = block_len(a, i);
+        const int pfx = hc_pfx_of(a, i);
+        if (pfx < 0) continue;
+        const int n = pfx + block_len(a, i);
         int nPad = (n + 1 + 1023) & ~1023;
         if (nPad > a.h12ChainStride) nPad = (int)a.h12ChainStride;
-        hc12_build_lists(a.src + (int64_t)i * a.srcStride, n, a.h12Offsets + (size_t)g * kHcHashEntries,
+        hc12_build_lists(a.src + (int64_t)i * a.srcStride - pfx, n, a.h12Offsets + (size_t)g * kHcHashEntries,
                          a.h12Chain + (int64_t)g * a.h12ChainStride, a.h12Rank + (int64_t)g * a.h12ChainStride,
-                         a.h12List + (int64_t)g * (a.h12ChainStride + 8) + 8, nPad, lastT, curT);
+                         a.h12List + (int64_t)g * (a.h12ChainStride + 8) + 8, nPad, lastT, curT, pfx > 3 ? pfx - 3 : 0, pfx);
     }
 }
 
@@ -756,7 +781,10 @@ __device__ __forceinline__ HcWork lz_work(const CodecArgs& a, int g)
     if (a.level >= 10) w.opt = hc_work_of(a).opt;                           // levels 10..11: the wave's price table (its slot of the HC workspace)
     return hc_with_pre(w, a, g);
 }
-__global__ __launch_bounds__(64) void k_hc_lazy(CodecArgs a)
+// kD: the call's blocks have external segments in front of them (a.hcPfx: dictionary / linked blocks, every level 3..12; lz4hc.c:
+// 1438-1461, :1626-1720); chain and lists then cover segment + block.  A kernel of its own, so that the independent blocks'
+// kernel does not carry the segment rules (and level 12's parameters).
+template <bool kD> __global__ __launch_bounds__(64) void k_hc_lazy(CodecArgs a)
 {
     const int items = a.nBlocks * a.lzSegs;
     const bool broken = plz4_readfirstlane(*(volatile int32_t*)a.h12Err) != 0;
@@ -764,27 +792,29 @@ __global__ __launch_bounds__(64) void k_hc_lazy(CodecArgs a)
         const int g = it / a.lzSegs, j = it - g * a.lzSegs;                  // (a block's segments are taken one after the other)
         const int i = a.blk0 + g;
         const int n = block_len(a, i);
-        if (broken || n < 0 || n > a.l1MaxLen) continue;
+        const int pfx = kD ? hc_pfx_of(a, i) : 0;
+        if (broken || n < 0 || n > a.l1MaxLen || pfx < 0) continue;
         const int segs = lz_segments(n, a.lzSegs, a.lzMinSeg);
         if (j >= segs) continue;
-        hc_lazy_segment(a.src + (int64_t)i * a.srcStride, n, a.level, lz_work(a, g), segs, j,
-                        a.lzRec + (int64_t)g * a.lzRecStride, a.lzMeta + (int64_t)g * a.lzSegs, a.lzStarts + (int64_t)g * a.lzSegs * kLzStarts);
+        hc_lazy_segment<kD>(a.src + (int64_t)i * a.srcStride, n, a.level, lz_work(a, g), segs, j,
+                            a.lzRec + (int64_t)g * a.lzRecStride, a.lzMeta + (int64_t)g * a.lzSegs, a.lzStarts + (int64_t)g * a.lzSegs * kLzStarts, pfx);
     }
 }
-__global__ __launch_bounds__(64) void k_hc_stitch(CodecArgs a)
+template <bool kD> __global__ __launch_bounds__(64) void k_hc_stitch(CodecArgs a)
 {
     const bool broken = plz4_readfirstlane(*(volatile int32_t*)a.h12Err) != 0;
     for (int g = next_block(a.queue); g < a.nBlocks; g = next_block(a.queue)) {
         const int i = a.blk0 + g;
         const int n = block_len(a, i);
         LzPiece* const pieces = a.lzPieces + (int64_t)g * 2 * a.lzSegs;
-        int lastAnchor = 0, nseq = -1, segs = 0;                             // -1: a block the workspace was not sized for
+        int lastAnchor = 0, nseq = -1, segs = 0;                             // -1: a block the workspace was not sized for, or one that is not this path's
+        const int pfx = kD ? hc_pfx_of(a, i) : 0;
         if (broken) nseq = kSeqEngineFailed;                                 // the search phase gave up: its F is not to be trusted
-        else if (n >= 0 && n <= a.l1MaxLen) {
+        else if (n >= 0 && n <= a.l1MaxLen && pfx >= 0) {
             segs = lz_segments(n, a.lzSegs, a.lzMinSeg);
-            nseq = hc_lazy_stitch(a.src + (int64_t)i * a.srcStride, n, a.level, lz_work(a, g), segs,
-                                  a.lzRec + (int64_t)g * a.lzRecStride, a.lzBridge + (int64_t)g * a.lzRecStride,
-                                  a.lzMeta + (int64_t)g * a.lzSegs, a.lzStarts + (int64_t)g * a.lzSegs * kLzStarts, pieces, &lastAnchor);
+            nseq = hc_lazy_stitch<kD>(a.src + (int64_t)i * a.srcStride, n, a.level, lz_work(a, g), segs,
+                                      a.lzRec + (int64_t)g * a.lzRecStride, a.lzBridge + (int64_t)g * a.lzRecStride,
+                                      a.lzMeta + (int64_t)g * a.lzSegs, a.lzStarts + (int64_t)g * a.lzSegs * kLzStarts, pieces, &lastAnchor, pfx);
         }
         if ((threadIdx.x & 63u) == 0) {
             for (int k = 2 * segs; k < 2 * a.lzSegs; ++k) pieces[k].cnt = 0;
@@ -1078,6 +1108,8 @@ struct plz4hip_ctx {
     // levels 3..11 on independent blocks: the list builder of the next group of blocks runs on this stream beside the walk of the
     // current one (launch_hc)
     hipStream_t  hcBuildStream = nullptr; hipEvent_t evHcFork = nullptr, evHcHist = nullptr, evHcChain[2] = {nullptr, nullptr}, evHcFree[2] = {nullptr, nullptr};
+    // HC levels 3..12 with a dictionary / linked blocks on the list path: the blocks' segment lengths (k_hc_ext_prep); one HC job at a time
+    int32_t*     d_hcPfx = nullptr; int hcPfxCap = 0; int hcLazyExWaves = 0;
     // plz4hip_dev_compress: the sanitised block lengths of the last call.  One job at a time like the workspaces: a call on another
     // stream waits (on the device) for the event behind the last job's kernels before it overwrites the copy.
     int32_t*     d_lenCopy = nullptr; int lenCopyCap = 0;
@@ -1342,12 +1374,29 @@ int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLe
         if (int rc = launch_l1(c, s, a, nb, maxLen, rawMode, nullptr, &declined)) return rc;
         if (!declined) return PLZ4HIP_OK;
     }
-    const bool lazy = use_lazy(a, maxLen);
+    // levels 3..12 with a dictionary and/or linked blocks, blocks up to 4 MiB (round 4): the same route as the lazy levels -- chain and
+    // lists over segment + block, the walk in segments, stitched, records through the emit stage -- with the segment rules of the
+    // reference kept in the finders (lz4hc_lazy_device.inl, kD); level 12 walks its optimal parser there as well.  Only the blocks
+    // <= 4 KiB under a dictionary context (usingDictCtxHc: two sets of tables) keep the one-thread parser, launched behind.
+    const bool lazyEx = a.hcEx && a.level >= 3 && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_EXT_OFF") == nullptr;
+    const bool lazy = use_lazy(a, maxLen) || lazyEx;
     if (lazy || use_h12(a, maxLen)) {
         // level 12 up to 4 MiB: its parser in segments as well (records; larger raw blocks keep the one-wave parser that writes bytes)
         const bool seg12 = !lazy && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC12_SEG_OFF") == nullptr;
         H12Plan pl;
-        if (int rc = plan_h12(c, nb, maxLen, &pl, lazy || seg12, !lazy)) return rc;
+        if (int rc = plan_h12(c, nb, maxLen + (lazyEx ? 65536 : 0), &pl, lazy || seg12, !lazy)) return rc;
+        if (lazyEx) {
+            if (nb > c->hcPfxCap) {
+                if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));
+                if (c->d_hcPfx) hipFree(c->d_hcPfx);
+                c->d_hcPfx = nullptr; c->hcPfxCap = 0;
+                if (hipMalloc((void**)&c->d_hcPfx, (size_t)nb * 4 + 1024) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "HC segment lengths");
+                c->hcPfxCap = nb + 256;
+            }
+            a.hcPfx = c->d_hcPfx; a.rawMode = rawMode; a.nBlocks = nb; a.blk0 = 0;
+            a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+            hipLaunchKernelGGL(k_hc_ext_prep, dim3(grid_for(nb, c->cus * 8)), dim3(64), 0, s, a);
+        }
         a.h12Chain = (uint16_t*)(c->d_h12 + 256); a.h12ChainStride = pl.chainStride;
         a.h12Rank = (uint32_t*)(c->d_h12 + pl.offRank); a.h12List = (uint32_t*)(c->d_h12 + pl.offList);
         a.h12Offsets = (uint32_t*)(c->d_h12 + pl.offOffsets);
@@ -1358,8 +1407,10 @@ int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLe
             if (lazy && a.level >= 10) { if (int rc = ensure_hc(c)) return rc; a.hcWork = c->d_hc; }
             if (!c->hcLazyWaves) {
                 int per = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc_lazy, 64, 0) != hipSuccess || per < 1) per = 8;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc_lazy<false>, 64, 0) != hipSuccess || per < 1) per = 8;
                 c->hcLazyWaves = c->cus * per;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_hc_lazy<true>, 64, 0) != hipSuccess || per < 1) per = 8;
+                c->hcLazyExWaves = c->cus * per;
             }
             a.l1MaxLen = maxLen; a.l1Seq = (uint64_t*)a.h12F; a.l1SeqStride = pl.fStride; a.l1MaxChunks = pl.maxChunks; a.l1Bk = nullptr;
             a.l1Info = (SeqInfo*)(c->d_h12 + pl.offInfo);
@@ -1467,11 +1518,14 @@ int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLe
                     a.queue = next_queue(c, s, &e); HIPCHK(c, e);
                     hipLaunchKernelGGL(k_hc12_stitch, dim3(grid_for(ng, c->h12SegWaves)), dim3(64), 0, s, a);
                 } else {
-                int lzWaves = a.level >= 10 && c->hcWaves < c->hcLazyWaves ? c->hcWaves : c->hcLazyWaves;   // (a price table per wave)
+                const int resident = lazyEx ? c->hcLazyExWaves : c->hcLazyWaves;
+                int lzWaves = a.level >= 10 && c->hcWaves < resident ? c->hcWaves : resident;   // (a price table per wave)
                 if (overlap && lzWaves > 2 * c->cus) lzWaves -= c->cus;                    // a wave slot (and its registers) per CU for the builder
-                hipLaunchKernelGGL(k_hc_lazy, dim3(grid_for(ng * a.lzSegs, lzWaves)), dim3(64), 0, s, a);
+                if (lazyEx) hipLaunchKernelGGL(k_hc_lazy<true>, dim3(grid_for(ng * a.lzSegs, lzWaves)), dim3(64), 0, s, a);
+                else        hipLaunchKernelGGL(k_hc_lazy<false>, dim3(grid_for(ng * a.lzSegs, lzWaves)), dim3(64), 0, s, a);
                 a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-                hipLaunchKernelGGL(k_hc_stitch, dim3(grid_for(ng, lzWaves)), dim3(64), 0, s, a);
+                if (lazyEx) hipLaunchKernelGGL(k_hc_stitch<true>, dim3(grid_for(ng, lzWaves)), dim3(64), 0, s, a);
+                else        hipLaunchKernelGGL(k_hc_stitch<false>, dim3(grid_for(ng, lzWaves)), dim3(64), 0, s, a);
                 }
                 hipLaunchKernelGGL(k_hc_gather, dim3(ng >= 1024 ? 4 : 16, ng), dim3(256), 0, s, a);
                 int wg = (16384 / ng) / 4;                                  // emit: waves per block so that a small call still spreads over the chip
@@ -1492,6 +1546,16 @@ int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLe
                 if (int rc = build(sb, x, true, false)) return rc;
                 HIPCHK(c, hipEventRecord(c->evHcHist, sb));
             }
+        }
+        if (lazyEx && (a0.dict != nullptr || a0.dictLen >= 0)) {
+            // the blocks <= 4 KiB under the dictionary context (hcPfx < 0; the emit stage has laid them down as stored records in the
+            // meantime): the one-thread parser over the context's tables writes them now
+            if (int rc = ensure_hc(c)) return rc;
+            CodecArgs x = a0; x.hcWork = c->d_hc; x.blk0 = 0; x.nBlocks = nb; x.h12Chain = nullptr; x.h12Rank = nullptr; x.h12List = nullptr;
+            x.queue = next_queue(c, s, &e); HIPCHK(c, e);
+            if (rawMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, x);
+            else         hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, x);
+            HIPCHK(c, hipGetLastError());
         }
     } else {
         if (int rc = ensure_hc(c)) return rc;
@@ -1792,6 +1856,7 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     if (c->l1Pending) hipEventSynchronize(c->l1Done);
     if (c->l1.d) hipFree(c->l1.d);
     if (c->d_lenCopy) hipFree(c->d_lenCopy);
+    if (c->d_hcPfx) hipFree(c->d_hcPfx);
     if (c->lenDone) hipEventDestroy(c->lenDone);
     if (c->l1Done) hipEventDestroy(c->l1Done);
     if (c->hcDone) hipEventDestroy(c->hcDone);

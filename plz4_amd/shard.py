@@ -77,7 +77,8 @@ def gather_frame_body(body: torch.Tensor, rec_len: torch.Tensor, rank: int, worl
         scratch["recv"] = torch.empty(2 * max(world - 1, 1) * need, dtype=torch.uint8, device=dev)
         scratch["cap"] = need; scratch["world"] = world
     if scratch.get("frame_cap", 0) < sum(totals):
-        scratch["frame"] = torch.empty(int(sum(totals) * 1.02) + (1 << 16), dtype=torch.uint8, device=dev)
+        # (sized from the gathered lengths, which are exact: no slack beyond a margin for the mover's 16-byte stores)
+        scratch["frame"] = torch.empty(sum(totals) + (1 << 16), dtype=torch.uint8, device=dev)
         scratch["frame_cap"] = scratch["frame"].numel()
     cap = scratch["cap"]
 

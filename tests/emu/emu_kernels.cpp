@@ -167,7 +167,8 @@ namespace {
 struct H12Emu {
     uint8_t* padded; uint16_t* chain; uint32_t* rank; uint32_t* listBase; uint32_t* offsets; int n, nPos, nPad;
     plz4::Hc12Tabs tabs;
-    H12Emu(const uint8_t* src, int n_) : n(n_)
+    // [skipLo, skipHi): positions that are never inserted (an external segment's last three)
+    H12Emu(const uint8_t* src, int n_, int skipLo = 0, int skipHi = 0) : n(n_)
     {
         using namespace plz4;
         nPos = n - kMfLimit + 1 > 0 ? n - kMfLimit + 1 : 0;
@@ -181,11 +182,11 @@ struct H12Emu {
         offsets = (uint32_t*)calloc(kHcHashEntries, 4);
         // what the histogram kernel does: how many positions each hash has, then where its run starts
         const int nIns = n >= 4 ? n - 3 : 0;
-        for (int p = 0; p < nIns; ++p) offsets[hc12_hash(ld32u(padded + p))]++;
+        for (int p = 0; p < nIns; ++p) if (!(p >= skipLo && p < skipHi)) offsets[hc12_hash(ld32u(padded + p))]++;
         uint32_t run = 0;
         for (int h = 0; h < kHcHashEntries; ++h) { const uint32_t c = offsets[h]; offsets[h] = run; run += c; }
         uint32_t* lastT = (uint32_t*)malloc(kHcHashEntries / 2 * 4); uint32_t* curT = (uint32_t*)malloc(kHcHashEntries / 2 * 4);
-        hc12_build_lists(padded, n, offsets, chain, rank, listBase + 8, nPad, lastT, curT);
+        hc12_build_lists(padded, n, offsets, chain, rank, listBase + 8, nPad, lastT, curT, skipLo, skipHi);
         free(lastT); free(curT);
         tabs.src = padded; tabs.chain = chain; tabs.rank = rank; tabs.list = listBase + 8;
     }
@@ -341,13 +342,45 @@ extern "C" int emu_compress_hc_lazy(const uint8_t* src, int n, uint8_t* dst, int
     uint64_t* starts = (uint64_t*)malloc((size_t)segs * kLzStarts * 8);
     LzSegMeta* meta = (LzSegMeta*)malloc(sizeof(LzSegMeta) * (size_t)segs);
     LzPiece* pieces = (LzPiece*)malloc(sizeof(LzPiece) * 2 * (size_t)segs);
-    for (int j = segs - 1; j >= 0; --j) hc_lazy_segment(E.padded, n, level, w, segs, j, rec, meta, starts);
+    for (int j = segs - 1; j >= 0; --j) hc_lazy_segment<false>(E.padded, n, level, w, segs, j, rec, meta, starts);
     int lastAnchor = 0;
-    const int nseq = hc_lazy_stitch(E.padded, n, level, w, segs, rec, bridge, meta, starts, pieces, &lastAnchor);
+    const int nseq = hc_lazy_stitch<false>(E.padded, n, level, w, segs, rec, bridge, meta, starts, pieces, &lastAnchor);
     uint64_t* seq = (uint64_t*)malloc(((size_t)n / 4 + 64) * 8);
     for (int k = 0; k < 2 * segs; ++k) for (int i = 0; i < pieces[k].cnt; ++i) seq[pieces[k].dst + i] = pieces[k].src[i];
     const int r = emu_emit_records(E.padded, n, seq, nseq, lastAnchor, dst, cap);
     free(seq); free(rec); free(bridge); free(starts); free(meta); free(pieces);
+    return r;
+}
+
+// HC levels 3..12 behind an external segment as the kernels run them (a linked block, or a block > 4 KiB under an attached
+// dictionary): chain and lists over segment + block (the segment's last three positions left out), the level's walk in segments
+// with the segment-aware finders, stitched, records through the emit stage.
+extern "C" int emu_compress_hc_lazy_ext(const uint8_t* src, int n, uint8_t* dst, int cap, int level, const uint8_t* seg, int segLen, int maxSegs, int minSeg)
+{
+    using namespace plz4;
+    if (n < 0 || n > kSeqMaxBlock || segLen < 0 || segLen > 65536) return -1;
+    uint8_t* cat = (uint8_t*)calloc((size_t)segLen + (size_t)n + 64, 1);
+    if (segLen) memcpy(cat, seg, (size_t)segLen);
+    if (n) memcpy(cat + segLen, src, (size_t)n);
+    const int N = segLen + n;
+    H12Emu E(cat, N, segLen > 3 ? segLen - 3 : 0, segLen);
+    static thread_local uint8_t* ows = nullptr;
+    if (!ows) ows = (uint8_t*)malloc(kHcWorkBytes);
+    HcWork w = emu_hc_work(ows);
+    w.pre = E.chain; w.rank = E.rank; w.list = E.listBase + 8;
+    const uint8_t* const blk = E.padded + segLen;
+    const int segs = lz_segments(n, maxSegs, minSeg), segCap = lz_seg_cap(lz_seg_len(n, segs));
+    uint64_t* rec = (uint64_t*)malloc((size_t)segs * segCap * 8), *bridge = (uint64_t*)malloc((size_t)segs * segCap * 8);
+    uint64_t* starts = (uint64_t*)malloc((size_t)segs * kLzStarts * 8);
+    LzSegMeta* meta = (LzSegMeta*)malloc(sizeof(LzSegMeta) * (size_t)segs);
+    LzPiece* pieces = (LzPiece*)malloc(sizeof(LzPiece) * 2 * (size_t)segs);
+    for (int j = segs - 1; j >= 0; --j) hc_lazy_segment<true>(blk, n, level, w, segs, j, rec, meta, starts, segLen);
+    int lastAnchor = 0;
+    const int nseq = hc_lazy_stitch<true>(blk, n, level, w, segs, rec, bridge, meta, starts, pieces, &lastAnchor, segLen);
+    uint64_t* seq = (uint64_t*)malloc(((size_t)n / 4 + 64) * 8);
+    for (int k = 0; k < 2 * segs; ++k) for (int i = 0; i < pieces[k].cnt; ++i) seq[pieces[k].dst + i] = pieces[k].src[i];
+    const int r = emu_emit_records(blk, n, seq, nseq, lastAnchor, dst, cap);
+    free(seq); free(rec); free(bridge); free(starts); free(meta); free(pieces); free(cat);
     return r;
 }
 

@@ -1,6 +1,9 @@
 """One-off fuzz: the device HC source with dictionaries / linked blocks (compiled for the CPU by tests/emu) against the real
 liblz4 in oracle/_ref driven the way clz4.go drives it (StreamCtxHC, StreamLinkedCtxHC), levels 2..12.
-Not part of the test-suite (takes minutes); run from the repo root:  python tests/fuzz/fuzz_hc_dict.py [iters] [seed]"""
+Not part of the test-suite (takes minutes); run from the repo root:  python tests/fuzz/fuzz_hc_dict.py [iters] [seed]
+PLZ4_FUZZ_LISTS=1: the blocks behind an external segment (linked blocks, blocks > 4 KiB under a dictionary) at levels 3..12 take
+the path the kernels run since round 4 -- chain and lists over segment + block, the walk in 1..16 segments, stitched, record emit
+(emu_compress_hc_lazy_ext) -- instead of the one-thread parsers of lz4hc_device.inl."""
 import os
 import sys
 
@@ -40,6 +43,17 @@ def mode_for(n):
     return 1 if n > 4096 else 2
 
 
+LISTS = os.environ.get("PLZ4_FUZZ_LISTS") == "1"
+
+
+def with_segment(emu, rng, b, cap, lvl, seg, mode):
+    """One block under the kernels' priming rule `mode` (1: external segment, 2: dictionary context)."""
+    if LISTS and mode == 1 and lvl >= 3:
+        segs, minseg = [(1, 65536), (4, 1000), (16, 300), (64, 100)][int(rng.integers(0, 4))]
+        return emu.compress_hc_lazy_ext(b, cap, lvl, seg, segs, minseg)
+    return emu.compress_hc_dict(b, cap, lvl, seg, mode)
+
+
 def main(iters=200, seed=11, levels=tuple(range(2, 13))):
     emu, ref, orc = Emu(), Ref(), Oracle()
     rng = np.random.default_rng(seed)
@@ -65,7 +79,7 @@ def main(iters=200, seed=11, levels=tuple(range(2, 13))):
             for b in blocks:
                 for cap in (orc.bound(b.size), b.size, max(b.size // 2, 1)):
                     a, da = comp(b, cap)
-                    r, dr = emu.compress_hc_dict(b, cap, lvl, dtrunc, mode_for(b.size))
+                    r, dr = with_segment(emu, rng, b, cap, lvl, dtrunc, mode_for(b.size))
                     tot += 1
                     if a != r or not np.array_equal(da, dr):
                         bad += 1; print("INDIE MISMATCH it", it, "kind", kind, "lvl", lvl, "dlen", dlen, "n", b.size, "cap", cap, a, r)
@@ -78,9 +92,9 @@ def main(iters=200, seed=11, levels=tuple(range(2, 13))):
                     cap = max(b.size, 1)
                     a, da = lcomp(b, cap, tail)
                     if tail is not None:
-                        r, dr = emu.compress_hc_dict(b, cap, lvl, tail, 1)
+                        r, dr = with_segment(emu, rng, b, cap, lvl, np.ascontiguousarray(tail), 1)
                     elif use_dict:
-                        r, dr = emu.compress_hc_dict(b, cap, lvl, dtrunc, mode_for(b.size))
+                        r, dr = with_segment(emu, rng, b, cap, lvl, dtrunc, mode_for(b.size))
                     else:
                         r, dr = emu.compress_hc(b, cap, lvl)
                     tot += 1

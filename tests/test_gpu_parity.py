@@ -540,6 +540,12 @@ def test_gpu_bench_modes_run_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert "configs[2]" in line["config"]["workload"] and line["value"] > 0 and line["roofline"]["kernel"] == "k_decode_rec"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--blocks", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+                          "--gather", "none"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["config"]["gather"] == "none" and line["ms"]["frame_gather"] < 0.5 and "gathered_frame" not in line["memory_gib"]["plan"]
+    assert "memory plan, GiB, for 8 ranks" in out.stderr                      # the dry run logs what rank 0 of a full node would hold
     for dup in ("1", "0"):                                                   # the duplex step and the serial one, gather path included
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--blocks", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                               "--duplex", dup], env=env, capture_output=True, text=True, timeout=600)

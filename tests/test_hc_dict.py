@@ -65,6 +65,43 @@ def test_emu_hc_dict_vs_reference_streams(ref, orc, emu):
                         assert g_ == w, (name, bsz, lvl, linked, d is not None, i)
 
 
+def _emu_records_lists(emu, orc, blocks, bsz, level, linked, dct, segs, min_seg):
+    """As _emu_records, with the blocks behind an external segment on the path the kernels run since round 4 at levels 3..12: chain
+    and lists over segment + block, the level's walk in `segs` segments, stitched, records through the emit stage."""
+    d = None if dct is None else np.ascontiguousarray(dct[-65536:])
+    out, prev = [], None
+    for b in blocks:
+        if linked and prev is not None:
+            r, c = emu.compress_hc_lazy_ext(b, bsz, level, np.ascontiguousarray(prev[-65536:]), segs, min_seg)
+        elif d is not None and b.size > 4096:
+            r, c = emu.compress_hc_lazy_ext(b, bsz, level, d, segs, min_seg)
+        elif d is not None:
+            r, c = emu.compress_hc_dict(b, bsz, level, d, 2)
+        else:
+            r, c = emu.compress_hc_lazy_ext(b, bsz, level, np.zeros(0, np.uint8), segs, min_seg)
+        out.append(hcdict.record(orc, r, c, b, True)); prev = b
+    return out
+
+
+def test_emu_hc_dict_on_the_lists_vs_reference_streams(ref, orc, emu):
+    """Levels 3..12 with a dictionary / linked blocks as the kernels run them since round 4 (k_hc_ext_prep -> k_hc12_hist ->
+    k_hc12_chain -> k_hc_lazy<true> -> k_hc_stitch<true> -> emit): against the real liblz4 streams, one walk and sixteen segments of
+    300 bytes (walks that meet late or never).  tests/fuzz/fuzz_hc_dict.py with PLZ4_FUZZ_LISTS=1 is the long version."""
+    user = synth.text(70000, seed=9)
+    pat = np.tile(np.frombuffer(b"abcabcab", np.uint8), 9000)
+    for name, dct, whole in (("text", user, synth.text(150000, seed=10)), ("pattern", pat[:50001], pat[50001:]),
+                             ("structured", corpus.structured(30000, 3), corpus.structured(100000, 3)), ("tiny-dict", user[:3], synth.text(50000, seed=11))):
+        for bsz in (4096, 40000):
+            blocks = [np.ascontiguousarray(whole[o:o + bsz]) for o in range(0, min(whole.size, 3 * bsz + 700), bsz)]
+            for lvl in (3, 5, 9, 10, 12):
+                for linked, d in ((True, dct), (True, None), (False, dct)):
+                    want, _ = hcdict.ref_records(ref, orc, blocks, bsz, lvl, linked, d)
+                    for segs, min_seg in ((1, 65536), (16, 300)):
+                        got = _emu_records_lists(emu, orc, blocks, bsz, lvl, linked, d, segs, min_seg)
+                        for i, (g_, w) in enumerate(zip(got, want)):
+                            assert g_ == w, (name, bsz, lvl, linked, d is not None, segs, i)
+
+
 def test_emu_hc_dict_golden_digests(orc, emu):
     g, user, bsz, frame, indie = _golden()
     for lvl in (2, 4, 9, 11):                                            # the GPU test covers every level
@@ -125,6 +162,27 @@ def test_gpu_hc_dict_vs_reference_streams(ref, orc, eng):
         want, _ = hcdict.ref_records(ref, orc, blocks, bsz, lvl, True, None)
         got = eng.encode_records_ex(blocks, bsz, True, linked=True, level=lvl)
         assert [g_.tobytes() for g_ in got] == want, lvl
+
+
+@pytest.mark.gpu
+def test_gpu_hc_linked_full_size_blocks_on_the_lists(ref, orc, monkeypatch):
+    """config 5 at the HC levels at its real size: 4 MiB linked blocks behind a 64 KiB dictionary (T and M data), levels 3, 9 and
+    12, against the real liblz4 streams -- on the list path (default) and, level 3, on the one-thread parsers it replaces
+    (PLZ4HIP_HC_EXT_OFF): the same bytes."""
+    from plz4_amd._native import Engine
+    bsz = 4 << 20
+    user = synth.text(65536, seed=99)
+    data = np.concatenate([synth.make("T", 2 * bsz, bsz), synth.make("M", 2 * bsz + 12345, bsz, seed=7)])
+    blocks = [np.ascontiguousarray(data[o:o + bsz]) for o in range(0, data.size, bsz)]
+    for lvl, off in ((3, False), (3, True), (9, False), (12, False)):
+        if off: monkeypatch.setenv("PLZ4HIP_HC_EXT_OFF", "1")
+        else: monkeypatch.delenv("PLZ4HIP_HC_EXT_OFF", raising=False)
+        want, _ = hcdict.ref_records(ref, orc, blocks, bsz, lvl, True, user)
+        e = Engine(0)
+        d = e.dict_create(np.ascontiguousarray(user))
+        got = e.encode_records_ex(blocks, bsz, True, linked=True, d=d, level=lvl)
+        assert [g_.tobytes() for g_ in got] == want, (lvl, off)
+        e.dict_destroy(d); e.close()
 
 
 @pytest.mark.gpu

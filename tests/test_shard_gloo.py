@@ -68,6 +68,21 @@ def test_round_robin_gather_in_pieces_world3():
     assert all(p.exitcode == 0 for p in procs)
 
 
+def test_round_robin_gather_uneven_pieces_world4():
+    """Four ranks whose bodies differ in size by two orders of magnitude (the M mix has period four in the block index, so with
+    four ranks one of them holds only stored blocks, one only runs of zeros): the senders take 1 ... 14 rounds of pieces, the
+    owner's receive group shrinks from round to round."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, 28, 64 << 10, q, 70000)) for r in range(4)]
+    for p in procs: p.start()
+    ok = q.get(timeout=240)
+    for p in procs: p.join(timeout=60)
+    assert ok == (True, True)
+    assert all(p.exitcode == 0 for p in procs)
+
+
 def test_piece_cuts():
     from plz4_amd import shard
     assert shard.piece_cuts([5, 5, 5, 5], 10) == [0, 2, 4]
