@@ -577,7 +577,10 @@ DEV uint32_t mid_hash8v(uint64_t v) { return (uint32_t)(((v << 8) * 582958181504
 // :673-675, at most down to the anchor and to the block's start).  Lanes 0..23 / 24..47: eight bytes each of the two forward
 // counts; 48..55 / 56..63: eight bytes each backwards.  Longer ones go on with the whole wave.
 struct MidMeasure { int ml1, ml2, bk1, bk2; };
-DEV MidMeasure mid_measure(const uint8_t* __restrict__ src, int P1, int D1, bool alt, int P2, int D2, int anchor, int matchlimit)
+// lim1: where the count of the match at P1 ends (matchlimit; the segment's end for a candidate inside an external segment: safeLen,
+// lz4hc.c:587-596, :637-646); lowPos: the catch-up does not take the match below this position (the block's first byte, :673:
+// `(ip - prefixPtr) > matchDistance`; 0 without a segment).
+DEV MidMeasure mid_measure(const uint8_t* __restrict__ src, int P1, int D1, bool alt, int P2, int D2, int anchor, int matchlimit, int lim1, int lowPos)
 {
     LV(int, cnt);
     LANES({
@@ -587,14 +590,14 @@ DEV MidMeasure mid_measure(const uint8_t* __restrict__ src, int P1, int D1, bool
         int c = 0;
         if (!second || alt) {
             if (fwd) {
-                const int off = 8 * j, valid = (matchlimit - P) - off;
+                const int off = 8 * j, valid = ((second ? matchlimit : lim1) - P) - off;
                 if (valid > 0) {
                     uint64_t x = ld64p_guard(src + P + off, valid) ^ ld64p_guard(src + P - D + off, valid);
                     if (valid < 8) x |= ~0ull << (8 * valid);
                     c = x ? (ctz64(x) >> 3) : 8;
                 }
             } else {
-                const int maxBack = min_(P - anchor, P - D), usable = maxBack - 8 * j;
+                const int maxBack = min_(P - anchor, max_(P - D - lowPos, 0)), usable = maxBack - 8 * j;
                 if (usable >= 8) {
                     const uint64_t x = ld64u(src + P - 8 * (j + 1)) ^ ld64u(src + P - D - 8 * (j + 1));
                     c = x ? (int)(__builtin_clzll(x) >> 3) : 8;
@@ -612,16 +615,16 @@ DEV MidMeasure mid_measure(const uint8_t* __restrict__ src, int P1, int D1, bool
         return 8 * j0 + RL(cnt, lo + j0);
     };
     r.ml1 = part(0, 24);
-    if (r.ml1 < 0) r.ml1 = 192 + wave_count_ptr(src + P1 + 192, src + P1 - D1 + 192, (matchlimit - P1) - 192);
+    if (r.ml1 < 0) r.ml1 = 192 + wave_count_ptr(src + P1 + 192, src + P1 - D1 + 192, (lim1 - P1) - 192);
     r.ml2 = 0; r.bk2 = 0;
     if (alt) {
         r.ml2 = part(24, 24);
         if (r.ml2 < 0) r.ml2 = 192 + wave_count_ptr(src + P2 + 192, src + P2 - D2 + 192, (matchlimit - P2) - 192);
         r.bk2 = part(56, 8);
-        if (r.bk2 < 0) r.bk2 = 64 + wave_back_ptr(src + P2 - 64, src + P2 - D2 - 64, min_(P2 - anchor, P2 - D2) - 64);
+        if (r.bk2 < 0) r.bk2 = 64 + wave_back_ptr(src + P2 - 64, src + P2 - D2 - 64, min_(P2 - anchor, max_(P2 - D2 - lowPos, 0)) - 64);
     }
     r.bk1 = part(48, 8);
-    if (r.bk1 < 0) r.bk1 = 64 + wave_back_ptr(src + P1 - 64, src + P1 - D1 - 64, min_(P1 - anchor, P1 - D1) - 64);
+    if (r.bk1 < 0) r.bk1 = 64 + wave_back_ptr(src + P1 - 64, src + P1 - D1 - 64, min_(P1 - anchor, max_(P1 - D1 - lowPos, 0)) - 64);
     return r;
 }
 
@@ -629,16 +632,54 @@ DEV MidMeasure mid_measure(const uint8_t* __restrict__ src, int P1, int D1, bool
 #define PLZ4_MID_WIDTH0 1
 #endif
 enum : int { kMidWidth0 = PLZ4_MID_WIDTH0 };       // lanes of the batch right behind a match (text: a match every other position); then 16, then 64
-DEV int hc_mid_parse(const uint8_t* __restrict__ src, const int n, uint32_t* h4t, uint32_t* h8t, uint64_t* seq, int* lastAnchor)
+#if defined(PLZ4_EMU)
+static inline void gmem_max(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
+#else
+__device__ __forceinline__ void gmem_max(uint32_t* p, uint32_t v) { atomicMax(p, v); }
+#endif
+// LZ4MID_fillHTable (lz4hc.c:477-503) over the external segment [0, size) by the whole wave: what LZ4_loadDictHC leaves in the two
+// (zeroed) tables.  The reference's two loops store in ascending order, the later store wins: a maximum per slot and loop; the
+// second loop (every position of the last 32 KiB into the long table) overrides the first (every third position into both), so its
+// values carry a mark until everything is in.
+DEV void hc_mid_prime(const uint8_t* __restrict__ src, const int size, uint32_t* h4t, uint32_t* h8t)
 {
+    if (size <= 8) return;
+    const int target = size - 8;
+    LANES({
+        for (int k = LANE; 3 * k < target; k += 64) {
+            const int p = 3 * k;
+            gmem_max(&h4t[mid_hash4v(ld32u(src + p))], (uint32_t)p + kHcBase);
+            gmem_max(&h8t[mid_hash8v(ld64u(src + p + 1))], (uint32_t)p + 1u + kHcBase);
+        }
+    })
+    WAVE_FENCE();
+    const int from = size > 32768 + 8 ? target - 32768 : 0;
+    LANES({ for (int p = from + LANE; p < target; p += 64) gmem_max(&h8t[mid_hash8v(ld64u(src + p))], ((uint32_t)p + kHcBase) | 0x80000000u); })
+    WAVE_FENCE();
+    LANES({ for (int i = LANE; i < 16384; i += 64) h8t[i] &= 0x7FFFFFFFu; })
+    WAVE_FENCE();
+}
+
+// kD: the block (`blk`, n bytes) has an external segment of pfxArg bytes right in front of it (a linked block after LZ4_loadDictHC, a
+// block > 4 KiB under an attached dictionary); positions count from the segment's first byte inside, records from the block's.  What
+// the reference does differently there: the tables start from LZ4MID_fillHTable over the segment; a candidate inside the segment
+// matches up to the segment's end only (safeLen, :587-596, :637-646) and gets neither the look at ip + 1 (:616) nor a catch-up (:673).
+template <bool kD = false>
+DEV int hc_mid_parse(const uint8_t* __restrict__ blk, const int n, uint32_t* h4t, uint32_t* h8t, uint64_t* seq, int* lastAnchor, const int pfxArg = 0)
+{
+    const int pfx = kD ? pfxArg : 0;
+    const uint8_t* const src = blk - pfx;
+    const int N = pfx + n;
+    const uint32_t prefixIdx = kHcBase + (uint32_t)pfx;
     *lastAnchor = 0;
     LANES({ for (int i = LANE; i < 16384; i += 64) { h4t[i] = 0u; h8t[i] = 0u; } })            // LZ4_initStreamHC: everything zero, lz4hc.c:1582-1583
     WAVE_FENCE();
-    SeqSink out; out.seq = seq; out.n = 0;
+    if (kD) hc_mid_prime(src, pfx, h4t, h8t);
+    SeqSink out; out.seq = seq; out.n = 0; out.bias = pfx;
     LANES({ out.buf[I_] = 0; })
-    const int mflimit = n - kMfLimit, matchlimit = n - kLastLiterals;
-    const uint32_t ilimitIdx = (uint32_t)(n - 8) + kHcBase;
-    int ip = 0, anchor = 0, width = kMidWidth0;
+    const int mflimit = N - kMfLimit, matchlimit = N - kLastLiterals;
+    const uint32_t ilimitIdx = (uint32_t)(N - 8) + kHcBase;
+    int ip = pfx, anchor = pfx, width = kMidWidth0;
     if (n < kMinLength || ip > mflimit) { return 0; }
 
     // a batch: the lanes' positions and their bytes (requested as soon as the batch's start is known: before the table fills of
@@ -692,8 +733,9 @@ DEV int hc_mid_parse(const uint8_t* __restrict__ src, const int n, uint32_t* h4t
             has8[I_] = false; has4[I_] = false;
             if (act[I_]) {
                 const uint32_t idx = (uint32_t)pk[I_] + kHcBase;
-                if (idx - t8[I_] <= 65535u) has8[I_] = ld32u(src + (t8[I_] - kHcBase)) == (uint32_t)a64[I_];
-                if (idx - t4[I_] <= 65535u) has4[I_] = ld32u(src + (t4[I_] - kHcBase)) == (uint32_t)a64[I_];
+                // (a candidate inside the segment is counted up to the segment's end: four bytes of it have to be there)
+                if (idx - t8[I_] <= 65535u && (!kD || t8[I_] >= prefixIdx || prefixIdx - t8[I_] >= 4u)) has8[I_] = ld32u(src + (t8[I_] - kHcBase)) == (uint32_t)a64[I_];
+                if (idx - t4[I_] <= 65535u && (!kD || t4[I_] >= prefixIdx || prefixIdx - t4[I_] >= 4u)) has4[I_] = ld32u(src + (t4[I_] - kHcBase)) == (uint32_t)a64[I_];
             }
         })
         const uint64_t hit = BALLOT(act[I_] && (has8[I_] || has4[I_]));
@@ -715,10 +757,13 @@ DEV int hc_mid_parse(const uint8_t* __restrict__ src, const int n, uint32_t* h4t
         int P = ip + m * step;
         const uint32_t ipIndex = (uint32_t)P + kHcBase;
         const bool via8 = RL(has8, m);
-        uint32_t dist = ipIndex - (via8 ? RL(t8, m) : RL(t4, m));
+        const uint32_t cand = via8 ? RL(t8, m) : RL(t4, m);
+        uint32_t dist = ipIndex - cand;
         const uint32_t pos8 = RL(x8, m), m2d = ipIndex + 1 - pos8;
-        const bool alt = !via8 && m2d <= 65535u && pos8 >= kHcBase && P < mflimit;            // one look at ip + 1 for a longer one, :616-650
-        const MidMeasure mm = mid_measure(src, P, (int)dist, alt, P + 1, (int)m2d, anchor, matchlimit);
+        // one look at ip + 1 for a longer one, :616-650 (only behind a short match inside the block, only at a candidate inside the block)
+        const bool alt = !via8 && m2d <= 65535u && pos8 >= prefixIdx && cand >= prefixIdx && P < mflimit;
+        const int lim1 = (kD && cand < prefixIdx) ? min_(matchlimit, P + (int)(prefixIdx - cand)) : matchlimit;
+        const MidMeasure mm = mid_measure(src, P, (int)dist, alt, P + 1, (int)m2d, anchor, matchlimit, lim1, pfx);
         int ml = mm.ml1, back = mm.bk1;
         if (alt && mm.ml2 > ml) {
             const uint32_t hx = RL(h8x, m);
@@ -739,14 +784,14 @@ DEV int hc_mid_parse(const uint8_t* __restrict__ src, const int n, uint32_t* h4t
             LV(uint32_t, f8); LV(uint32_t, f4);
             LANES({
                 const int at = LANE == 0 ? P + 1 : LANE == 1 ? P + 2 : LANE == 2 ? E - 5 : LANE == 3 ? E - 3 : LANE == 4 ? E - 2 : E - 1;
-                const bool on = LANE < 2 || (LANE < 6 && endOk && (LANE != 2 || E > 5));
+                const bool on = LANE < 2 || (LANE < 6 && endOk && (LANE != 2 || E - pfx > 5));
                 uint64_t v = 0;
                 if (on) v = LANE == 5 ? (uint64_t)ld32u(src + at) : ld64u(src + at);
                 f8[I_] = mid_hash8v(v); f4[I_] = mid_hash4v((uint32_t)v);
             })
             // (one lane makes all of them: its own stores are ordered, two lanes' stores to one slot are not)
             const uint32_t s0 = RL(f8, 0), s1 = RL(f8, 1), s2 = RL(f8, 2), s3 = RL(f8, 3), s4 = RL(f8, 4), q0 = RL(f4, 0), q4 = RL(f4, 4), q5 = RL(f4, 5);
-            const bool far = E > 5;
+            const bool far = E - pfx > 5;
             LANES({ if (LANE == 0) {
                 h8t[s0] = ipIndex + 1; h8t[s1] = ipIndex + 2; h4t[q0] = ipIndex + 1;
                 if (endOk) {
@@ -758,7 +803,7 @@ DEV int hc_mid_parse(const uint8_t* __restrict__ src, const int n, uint32_t* h4t
         }
     }
     out.finish();
-    *lastAnchor = anchor;
+    *lastAnchor = anchor - pfx;
     return out.n;
 }
 

@@ -891,15 +891,17 @@ __global__ __launch_bounds__(64) void k_hc12_stitch(CodecArgs a)
 
 // Level 2 on independent blocks: the batch walk over the two tables (hc_mid_parse, lz4hc_lazy_device.inl), one wave per block,
 // the tables in the wave's slot of the HC workspace; records out, the emit kernels of level 1 behind it.
-__global__ __launch_bounds__(64) void k_hc_mid(CodecArgs a)
+// kD: blocks behind external segments (a.hcPfx; dictionary / linked blocks): the tables start from LZ4MID_fillHTable over the segment
+template <bool kD> __global__ __launch_bounds__(64) void k_hc_mid(CodecArgs a)
 {
     uint32_t* const tabs = (uint32_t*)(a.hcWork + (size_t)blockIdx.x * kHcWorkBytes);
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
         const int gi = a.blk0 + i;
         const int n  = block_len(a, gi);
-        int lastAnchor = 0, nseq = -1;                                       // -1: a block the workspace was not sized for
-        if (n >= 0 && n <= a.l1MaxLen)
-            nseq = hc_mid_parse(a.src + (int64_t)gi * a.srcStride, n, tabs, tabs + 16384, a.l1Seq + (int64_t)i * a.l1SeqStride, &lastAnchor);
+        const int pfx = kD ? hc_pfx_of(a, gi) : 0;
+        int lastAnchor = 0, nseq = -1;                                       // -1: a block the workspace was not sized for, or one that is not this path's
+        if (n >= 0 && n <= a.l1MaxLen && pfx >= 0)
+            nseq = hc_mid_parse<kD>(a.src + (int64_t)gi * a.srcStride, n, tabs, tabs + 16384, a.l1Seq + (int64_t)i * a.l1SeqStride, &lastAnchor, pfx);
         if ((threadIdx.x & 63u) == 0) { SeqInfo inf; inf.nseq = nseq; inf.lastAnchor = lastAnchor; inf.total = 0; inf.stored = 0; a.l1Info[i] = inf; }
     }
 }
@@ -1366,37 +1368,54 @@ int launch_hc(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
 int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, bool* forked)
 {
     hipError_t e;
-    if (a.level == 2 && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_MID_OFF") == nullptr) {
-        // level 2, independent blocks up to 4 MiB: the staged call of level 1 with the level-2 walk as its parser
+    const auto prep_ext = [&]() -> int {                                    // the blocks' segments laid out, their lengths noted (k_hc_ext_prep)
+        if (nb > c->hcPfxCap) {
+            if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));
+            if (c->d_hcPfx) hipFree(c->d_hcPfx);
+            c->d_hcPfx = nullptr; c->hcPfxCap = 0;
+            if (hipMalloc((void**)&c->d_hcPfx, (size_t)nb * 4 + 1024) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "HC segment lengths");
+            c->hcPfxCap = nb + 256;
+        }
+        a.hcPfx = c->d_hcPfx; a.rawMode = rawMode; a.nBlocks = nb; a.blk0 = 0;
+        a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+        hipLaunchKernelGGL(k_hc_ext_prep, dim3(grid_for(nb, c->cus * 8)), dim3(64), 0, s, a);
+        return PLZ4HIP_OK;
+    };
+    const auto ctx_blocks = [&](const CodecArgs& a0) -> int {
+        // the blocks <= 4 KiB under a dictionary context (hcPfx < 0; the emit stage has laid them down as stored records in the
+        // meantime): the one-thread parser over the context's two sets of tables writes them now
+        if (a0.dict == nullptr && a0.dictLen < 0) return PLZ4HIP_OK;
+        if (int rc = ensure_hc(c)) return rc;
+        CodecArgs x = a0; x.hcWork = c->d_hc; x.blk0 = 0; x.nBlocks = nb; x.h12Chain = nullptr; x.h12Rank = nullptr; x.h12List = nullptr;
+        x.queue = next_queue(c, s, &e); HIPCHK(c, e);
+        if (rawMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, x);
+        else         hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, x);
+        HIPCHK(c, hipGetLastError());
+        return PLZ4HIP_OK;
+    };
+    const bool extOk = a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_EXT_OFF") == nullptr;
+    if (a.level == 2 && (!a.hcEx || extOk) && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_MID_OFF") == nullptr) {
+        // level 2, blocks up to 4 MiB: the staged call of level 1 with the level-2 walk as its parser (behind external segments too)
         if (int rc = ensure_hc(c)) return rc;
         a.hcWork = c->d_hc;
+        if (a.hcEx) { if (int rc = prep_ext()) return rc; }
         bool declined = false;
         if (int rc = launch_l1(c, s, a, nb, maxLen, rawMode, nullptr, &declined)) return rc;
-        if (!declined) return PLZ4HIP_OK;
+        if (!declined) return a.hcEx ? ctx_blocks(a) : PLZ4HIP_OK;
+        a.hcPfx = nullptr;                                                   // (no workspace: every block on the one-thread parser)
     }
     // levels 3..12 with a dictionary and/or linked blocks, blocks up to 4 MiB (round 4): the same route as the lazy levels -- chain and
     // lists over segment + block, the walk in segments, stitched, records through the emit stage -- with the segment rules of the
     // reference kept in the finders (lz4hc_lazy_device.inl, kD); level 12 walks its optimal parser there as well.  Only the blocks
     // <= 4 KiB under a dictionary context (usingDictCtxHc: two sets of tables) keep the one-thread parser, launched behind.
-    const bool lazyEx = a.hcEx && a.level >= 3 && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_EXT_OFF") == nullptr;
+    const bool lazyEx = extOk && a.level >= 3;
     const bool lazy = use_lazy(a, maxLen) || lazyEx;
     if (lazy || use_h12(a, maxLen)) {
         // level 12 up to 4 MiB: its parser in segments as well (records; larger raw blocks keep the one-wave parser that writes bytes)
         const bool seg12 = !lazy && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC12_SEG_OFF") == nullptr;
         H12Plan pl;
         if (int rc = plan_h12(c, nb, maxLen + (lazyEx ? 65536 : 0), &pl, lazy || seg12, !lazy)) return rc;
-        if (lazyEx) {
-            if (nb > c->hcPfxCap) {
-                if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));
-                if (c->d_hcPfx) hipFree(c->d_hcPfx);
-                c->d_hcPfx = nullptr; c->hcPfxCap = 0;
-                if (hipMalloc((void**)&c->d_hcPfx, (size_t)nb * 4 + 1024) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "HC segment lengths");
-                c->hcPfxCap = nb + 256;
-            }
-            a.hcPfx = c->d_hcPfx; a.rawMode = rawMode; a.nBlocks = nb; a.blk0 = 0;
-            a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-            hipLaunchKernelGGL(k_hc_ext_prep, dim3(grid_for(nb, c->cus * 8)), dim3(64), 0, s, a);
-        }
+        if (lazyEx) { if (int rc = prep_ext()) return rc; }
         a.h12Chain = (uint16_t*)(c->d_h12 + 256); a.h12ChainStride = pl.chainStride;
         a.h12Rank = (uint32_t*)(c->d_h12 + pl.offRank); a.h12List = (uint32_t*)(c->d_h12 + pl.offList);
         a.h12Offsets = (uint32_t*)(c->d_h12 + pl.offOffsets);
@@ -1547,16 +1566,7 @@ int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLe
                 HIPCHK(c, hipEventRecord(c->evHcHist, sb));
             }
         }
-        if (lazyEx && (a0.dict != nullptr || a0.dictLen >= 0)) {
-            // the blocks <= 4 KiB under the dictionary context (hcPfx < 0; the emit stage has laid them down as stored records in the
-            // meantime): the one-thread parser over the context's tables writes them now
-            if (int rc = ensure_hc(c)) return rc;
-            CodecArgs x = a0; x.hcWork = c->d_hc; x.blk0 = 0; x.nBlocks = nb; x.h12Chain = nullptr; x.h12Rank = nullptr; x.h12List = nullptr;
-            x.queue = next_queue(c, s, &e); HIPCHK(c, e);
-            if (rawMode) hipLaunchKernelGGL(k_encode_raw_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, x);
-            else         hipLaunchKernelGGL(k_encode_rec_hc, dim3(grid_for(nb, c->hcWaves)), dim3(64), 0, s, x);
-            HIPCHK(c, hipGetLastError());
-        }
+        if (lazyEx) { if (int rc = ctx_blocks(a0)) return rc; }
     } else {
         if (int rc = ensure_hc(c)) return rc;
         a.hcWork = c->d_hc; a.nBlocks = nb;
@@ -1722,7 +1732,8 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         const int ng = nb - g0 < per ? nb - g0 : per;
         a.blk0 = g0; a.nBlocks = ng;
         a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-        if (mid) hipLaunchKernelGGL(k_hc_mid, dim3(grid_for(ng, c->hcWaves)), dim3(64), 0, s, a);
+        if (mid && a.hcPfx) hipLaunchKernelGGL(k_hc_mid<true>, dim3(grid_for(ng, c->hcWaves)), dim3(64), 0, s, a);
+        else if (mid) hipLaunchKernelGGL(k_hc_mid<false>, dim3(grid_for(ng, c->hcWaves)), dim3(64), 0, s, a);
         else if (rider && g0 == 0) {
             // workgroups: what the device holds at once, unless neither role has that much to do
             int P = 1, D = 1, prio = 3;

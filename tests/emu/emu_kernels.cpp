@@ -400,6 +400,23 @@ extern "C" int emu_compress_hc_mid(const uint8_t* src, int n, uint8_t* dst, int 
     return r;
 }
 
+// ... and behind an external segment (a linked block, a block > 4 KiB under an attached dictionary)
+extern "C" int emu_compress_hc_mid_ext(const uint8_t* src, int n, uint8_t* dst, int cap, const uint8_t* seg, int segLen)
+{
+    using namespace plz4;
+    if (n < 0 || n > kSeqMaxBlock || segLen < 0 || segLen > 65536) return -1;
+    uint8_t* cat = (uint8_t*)calloc((size_t)segLen + (size_t)n + 64, 1);
+    if (segLen) memcpy(cat, seg, (size_t)segLen);
+    if (n) memcpy(cat + segLen, src, (size_t)n);
+    uint32_t* tabs = (uint32_t*)malloc(32768 * 4);
+    uint64_t* seq = (uint64_t*)malloc(((size_t)n / 4 + 64) * 8);
+    int lastAnchor = 0;
+    const int nseq = hc_mid_parse<true>(cat + segLen, n, tabs, tabs + 16384, seq, &lastAnchor, segLen);
+    const int r = emu_emit_records(cat + segLen, n, seq, nseq, lastAnchor, dst, cap);
+    free(seq); free(tabs); free(cat);
+    return r;
+}
+
 // diagnostics of the level-1 parser's pipeline (see plz4_emu_cnt in lz4_seq_device.inl); reset on read
 extern "C" void emu_parse_counters(unsigned long long* out8)
 {

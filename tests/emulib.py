@@ -125,12 +125,23 @@ class Emu:
     def compress_hc_lazy_ext(self, src, cap, level, seg, max_segs=1, min_seg=65536):
         """Levels 3..12 behind an external segment (a linked block, a block > 4 KiB under an attached dictionary) as the kernels
         run them: lists over segment + block, the walk in segments, stitched, record emit."""
+        if level == 2:
+            return self.compress_hc_mid_ext(src, cap, seg)
         self.L.emu_compress_hc_lazy_ext.restype = C.c_int
         self.L.emu_compress_hc_lazy_ext.argtypes = [u8p, C.c_int, u8p, C.c_int, C.c_int, u8p, C.c_int, C.c_int, C.c_int]
         dst = np.zeros(max(cap, 1) + 64, dtype=np.uint8)
         nul = C.cast(None, u8p)
         r = int(self.L.emu_compress_hc_lazy_ext(_ptr(src) if src.size else nul, src.size, _ptr(dst), cap, level,
                                                 _ptr(seg) if seg.size else nul, seg.size, max_segs, min_seg))
+        return r, dst[:max(r, 0)]
+
+    def compress_hc_mid_ext(self, src, cap, seg):
+        """Level 2 behind an external segment as the kernels run it (hc_mid_parse<true>: tables primed over the segment)."""
+        self.L.emu_compress_hc_mid_ext.restype = C.c_int
+        self.L.emu_compress_hc_mid_ext.argtypes = [u8p, C.c_int, u8p, C.c_int, u8p, C.c_int]
+        dst = np.zeros(max(cap, 1) + 64, dtype=np.uint8)
+        nul = C.cast(None, u8p)
+        r = int(self.L.emu_compress_hc_mid_ext(_ptr(src) if src.size else nul, src.size, _ptr(dst), cap, _ptr(seg) if seg.size else nul, seg.size))
         return r, dst[:max(r, 0)]
 
     def compress_hc_mid(self, src, cap):

@@ -48,7 +48,7 @@ LISTS = os.environ.get("PLZ4_FUZZ_LISTS") == "1"
 
 def with_segment(emu, rng, b, cap, lvl, seg, mode):
     """One block under the kernels' priming rule `mode` (1: external segment, 2: dictionary context)."""
-    if LISTS and mode == 1 and lvl >= 3:
+    if LISTS and mode == 1 and lvl >= 2:
         segs, minseg = [(1, 65536), (4, 1000), (16, 300), (64, 100)][int(rng.integers(0, 4))]
         return emu.compress_hc_lazy_ext(b, cap, lvl, seg, segs, minseg)
     return emu.compress_hc_dict(b, cap, lvl, seg, mode)
