@@ -24,6 +24,7 @@ __device__ unsigned long long plz4_stats[24];
 #include "lz4hc_device.inl"
 #include "lz4hc12_device.inl"
 #include "lz4hc_lazy_device.inl"
+#include "lz4_dx_device.inl"
 
 namespace {
 
@@ -76,6 +77,14 @@ struct CodecArgs {
     int             lzSegs, lzMinSeg;
     uint64_t*       lzRec;      uint64_t* lzBridge;  int64_t lzRecStride;     // records of the segments / of the walks into them, entries per block
     LzSegMeta*      lzMeta;     uint64_t* lzStarts;  LzPiece* lzPieces;       // per block: lzSegs, lzSegs * kLzStarts, 2 * lzSegs entries
+    // a few blocks decoded by the whole chip (lz4_dx_device.inl): per block, the chain table of its input (one entry per byte), the
+    // pointer table of its output (one per byte), the units of its segments, its state
+    uint64_t*       dxT;        int64_t dxTStride;
+    uint32_t*       dxPtr;      int64_t dxPtrStride;
+    DxUnit*         dxUnits;    int dxMaxSeg;   int dxRound;
+    DxInfo*         dxInfo;
+    const int64_t*  dxSrcOff;   const int32_t* dxLen;                       // records: where a block's payload starts in src and its size (-1: not this path's)
+    int32_t*        dxHashBad;                                              // records: the payload's xxh32 does not match (k_dx_rec_hash)
 };
 
 __device__ __forceinline__ int next_block(uint32_t* q)
@@ -916,9 +925,114 @@ __global__ __launch_bounds__(64) void k_hc_dict_prime(const uint8_t* dict, int l
     hc_prime_dict(dict, len, blockIdx.x == 0 ? 2 : 3, w);
 }
 
+// ---- LZ4_decompress_safe of a few blocks by the whole chip (lz4_dx_device.inl).  grid (segments, blocks) for the per-segment
+// kernels, (chunks of 1024 output bytes, blocks) for the per-byte ones; a block that any stage flags is decoded by k_decode_raw behind.
+__device__ __forceinline__ int dx_cap(const CodecArgs& a, int b) { return a.dstCap ? a.dstCap[b] : a.dstCapAll; }
+__device__ __forceinline__ const uint8_t* dx_src(const CodecArgs& a, int b) { return a.src + (a.dxSrcOff ? a.dxSrcOff[b] : (int64_t)b * a.srcStride); }
+__device__ __forceinline__ int dx_len(const CodecArgs& a, int b) { return a.dxLen ? a.dxLen[b] : a.srcLen[b]; }
+__global__ __launch_bounds__(64) void k_dx_tables(CodecArgs a)
+{
+    const int j = blockIdx.x, b = blockIdx.y;
+    const int n = dx_len(a, b);
+    {   // the pointer table starts as the identity: this workgroup's share of it
+        const int64_t share = (a.dxPtrStride + gridDim.x - 1) / gridDim.x;
+        uint32_t* const ptr = a.dxPtr + (int64_t)b * a.dxPtrStride;
+        const int64_t lo = (int64_t)j * share, hi = lo + share < a.dxPtrStride ? lo + share : a.dxPtrStride;
+        for (int64_t p = lo + (threadIdx.x & 63u); p < hi; p += 64) ptr[p] = (uint32_t)p;
+    }
+    if (n <= 0 || (int64_t)j * kDxSeg >= n || n > a.dxTStride - 64) return;           // (a block beyond what the tables were sized for is flagged by the stitch)
+    dx_segment_table(dx_src(a, b), n, j, a.dxT + (int64_t)b * a.dxTStride);
+}
+__global__ __launch_bounds__(64) void k_dx_stitch(CodecArgs a)
+{
+    const int b = blockIdx.x;
+    const int n = dx_len(a, b);
+    const int nseg = dx_segments(n);
+    int bad = (nseg > a.dxMaxSeg || n > a.dxTStride - 64 || dx_cap(a, b) > a.dxPtrStride - 64) ? 1 : dx_stitch(dx_src(a, b), n, dx_cap(a, b), a.dxT + (int64_t)b * a.dxTStride,
+                                                a.dxUnits + (int64_t)b * a.dxMaxSeg, nseg);
+    if ((threadIdx.x & 63u) == 0) {
+        DxInfo inf; inf.bad = bad; inf.outLen = 0; inf.tailFrom = dx_tail_from(nseg); inf.pad = 0;
+        for (int r = 0; r <= kDxRounds; ++r) inf.moved[r] = 0;
+        a.dxInfo[b] = inf;
+    }
+}
+__global__ __launch_bounds__(64) void k_dx_fill(CodecArgs a)
+{
+    const int j = blockIdx.x, b = blockIdx.y;
+    DxInfo* const inf = a.dxInfo + b;
+    if (inf->bad || j > inf->tailFrom) return;
+    const int jt = inf->tailFrom;
+    const DxUnit* const units = a.dxUnits + (int64_t)b * a.dxMaxSeg;
+    const DxUnit u = units[j];
+    if (j < jt && u.ip < 0) return;
+    const int64_t r = wave_dx_fill(dx_src(a, b), dx_len(a, b), a.dst + (int64_t)b * a.dstStride, dx_cap(a, b),
+                                   a.dxPtr + (int64_t)b * a.dxPtrStride, u.ip, u.op, u.stop, j == jt);
+    bool ok = r >= 0;
+    if (ok && j < jt) {                                              // where this unit stops is where the next one starts
+        int k = j + 1; while (k < jt && units[k].ip < 0) ++k;
+        ok = units[k].op == (int)r;
+    }
+    if ((threadIdx.x & 63u) == 0) { if (!ok) atomicOr(&inf->bad, 1); else if (j == jt) inf->outLen = (int)r; }
+}
+__global__ __launch_bounds__(256) void k_dx_jump(CodecArgs a)
+{
+    const int b = blockIdx.y, r = a.dxRound;
+    DxInfo* const inf = a.dxInfo + b;
+    if (inf->bad || (r > 0 && !inf->moved[r - 1])) return;
+    const int outLen = inf->outLen, p0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 256;
+    if (p0 >= outLen) return;
+    if (dx_jump(a.dxPtr + (int64_t)b * a.dxPtrStride, p0, outLen) && (threadIdx.x & 63u) == 0) inf->moved[r] = 1u;
+}
+__global__ __launch_bounds__(256) void k_dx_gather(CodecArgs a)
+{
+    const int b = blockIdx.y;
+    const DxInfo* const inf = a.dxInfo + b;
+    if (inf->bad) return;
+    const int outLen = inf->outLen, p0 = (blockIdx.x * 4 + (int)(threadIdx.x >> 6)) * 256;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // (records: the payload's checksum is verified beside this path, k_dx_rec_hash; frame.go:114-127 rejects before it decodes)
+        const bool hashBad = a.dxHashBad && a.dxHashBad[b];
+        a.result[b] = hashBad ? 0 : outLen;
+        if (a.status) a.status[b] = hashBad ? PLZ4HIP_BLK_HASH_MISMATCH : PLZ4HIP_BLK_OK;
+    }
+    if (p0 >= outLen) return;
+    dx_gather(a.dst + (int64_t)b * a.dstStride, a.dxPtr + (int64_t)b * a.dxPtrStride, p0, outLen);
+}
+
+// records on the few-block path: which records are compressed payloads of a sane size (FrameReader._read's checks, blk/frame.go:
+// 79-85; everything else -- stored blocks, size overflows -- is the one-wave kernel's, which runs for the flagged blocks behind)
+__global__ __launch_bounds__(256) void k_dx_rec_prep(CodecArgs a, int64_t* srcOff, int32_t* len)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.nBlocks) return;
+    const int64_t off = a.recOff ? a.recOff[i] : (int64_t)i * a.srcStride;
+    const int64_t recLen = a.recOff ? a.recOff[i + 1] - a.recOff[i] : (int64_t)a.srcLen[i];
+    int n = -1;
+    if (recLen >= 4) {
+        const uint32_t word = ld32u(a.src + off);
+        const int sz = (int)(word & 0x7FFFFFFFu);
+        if (!(word & 0x80000000u) && sz <= a.bsz && (int64_t)sz + 4 + (a.blockChecksum ? 4 : 0) <= recLen) n = sz;
+    }
+    srcOff[i] = off + 4; len[i] = n;
+}
+// ... and their block checksums (frame.go:114-127), one wave per record, on a stream of its own beside the decode
+__global__ __launch_bounds__(64) void k_dx_rec_hash(CodecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stagebuf[4096];
+    const int b = blockIdx.x;
+    const int n = a.dxLen[b];
+    int bad = 0;
+    if (n >= 0) {
+        const uint8_t* p = a.src + a.dxSrcOff[b];
+        bad = wave_xxh32_staged(p, n, stagebuf) != plz4_readfirstlane(ld32u(p + n));
+    }
+    if ((threadIdx.x & 63u) == 0) a.dxHashBad[b] = bad;
+}
+
 __global__ __launch_bounds__(64) void k_decode_raw(CodecArgs a)
 {
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        if (a.dxInfo && !a.dxInfo[i].bad) continue;                          // (answered by the few-block path)
         const int n   = a.srcLen[i];
         const int cap = a.dstCap ? a.dstCap[i] : a.dstCapAll;
         const int r   = wave_decode_block(a.src + (int64_t)i * a.srcStride, n, a.dst + (int64_t)i * a.dstStride, cap);
@@ -931,6 +1045,7 @@ __global__ __launch_bounds__(64) void k_decode_raw(CodecArgs a)
 __device__ __forceinline__ void decode_rec_loop(const CodecArgs& a, uint8_t* dl)
 {
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
+        if (a.dxInfo && !a.dxInfo[i].bad) continue;                          // (answered by the few-block path)
         const uint8_t* rec    = a.recOff ? a.src + a.recOff[i] : a.src + (int64_t)i * a.srcStride;
         const int64_t  recLen = a.recOff ? a.recOff[i + 1] - a.recOff[i] : (int64_t)a.srcLen[i];
         uint8_t*       out    = a.dst + (int64_t)i * a.dstStride;
@@ -1112,6 +1227,10 @@ struct plz4hip_ctx {
     hipStream_t  hcBuildStream = nullptr; hipEvent_t evHcFork = nullptr, evHcHist = nullptr, evHcChain[2] = {nullptr, nullptr}, evHcFree[2] = {nullptr, nullptr};
     // HC levels 3..12 with a dictionary / linked blocks on the list path: the blocks' segment lengths (k_hc_ext_prep); one HC job at a time
     int32_t*     d_hcPfx = nullptr; int hcPfxCap = 0; int hcLazyExWaves = 0;
+    // LZ4_decompress_safe of a few blocks by the whole chip (lz4_dx_device.inl): tables of one job at a time, ordered across streams
+    uint8_t*     d_dx = nullptr; size_t dxBytes = 0;
+    hipEvent_t   dxDone = nullptr; hipStream_t dxStream = nullptr; bool dxPending = false;
+    hipStream_t  dxHashStream = nullptr; hipEvent_t evDxFork = nullptr, evDxHash = nullptr;   // records: the block checksums beside the decode
     // plz4hip_dev_compress: the sanitised block lengths of the last call.  One job at a time like the workspaces: a call on another
     // stream waits (on the device) for the event behind the last job's kernels before it overwrites the copy.
     int32_t*     d_lenCopy = nullptr; int lenCopyCap = 0;
@@ -1372,6 +1491,12 @@ int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLe
         if (nb > c->hcPfxCap) {
             if (c->hcPending) HIPCHK(c, hipEventSynchronize(c->hcDone));
             if (c->d_hcPfx) hipFree(c->d_hcPfx);
+    if (c->dxPending) hipEventSynchronize(c->dxDone);
+    if (c->d_dx) hipFree(c->d_dx);
+    if (c->dxDone) hipEventDestroy(c->dxDone);
+    if (c->dxHashStream) { hipStreamSynchronize(c->dxHashStream); hipStreamDestroy(c->dxHashStream); }
+    if (c->evDxFork) hipEventDestroy(c->evDxFork);
+    if (c->evDxHash) hipEventDestroy(c->evDxHash);
             c->d_hcPfx = nullptr; c->hcPfxCap = 0;
             if (hipMalloc((void**)&c->d_hcPfx, (size_t)nb * 4 + 1024) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "HC segment lengths");
             c->hcPfxCap = nb + 256;
@@ -1786,6 +1911,78 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     return PLZ4HIP_OK;
 }
 
+// Enqueue the decode of nb blocks on s (a: everything but the queue filled in) -- raw blocks (LZ4_decompress_safe per block) or, with
+// `records`, frame records (FrameReader._read + BlkT.Decompress, blk/frame.go:54-127, blk.go:50-61).  maxIn / maxOut: upper bounds of
+// the blocks' compressed and decoded sizes known to the host (the lengths themselves may live on the device).
+// A call of few blocks is cut across the chip (lz4_dx_device.inl: 1 x 4 MiB in about a millisecond of kernels instead of the
+// 66 ms one wavefront needs; the records' block checksums are verified beside it on a stream of their own); blocks that path will
+// not answer for -- anything but a plainly valid compressed block -- and calls of many blocks, where one wave per block is the
+// better use of the chip, run the one-wave kernels.  PLZ4HIP_DX_MAX_BLOCKS (default 128; 0: off).
+int launch_decode(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int64_t maxIn, int64_t maxOut, bool records)
+{
+    hipError_t e;
+    int dxMax = 128;
+    if (const char* v = getenv("PLZ4HIP_DX_MAX_BLOCKS")) dxMax = atoi(v);
+    bool dx = nb <= dxMax && maxIn >= 16384 && maxIn <= (int64_t)(6 << 20) && maxOut >= 1;
+    a.dxInfo = nullptr; a.dxSrcOff = nullptr; a.dxLen = nullptr; a.dxHashBad = nullptr;
+    if (dx) {
+        const int64_t outB = maxOut < kDxMaxOut ? maxOut : kDxMaxOut;
+        const size_t tStride = round_up((size_t)maxIn + 64, 64), pStride = round_up((size_t)outB + 64, 1024);
+        const int maxSeg = (int)((maxIn + kDxSeg - 1) / kDxSeg);
+        const size_t offPtr = round_up((size_t)nb * tStride * 8, 256), offUnits = offPtr + round_up((size_t)nb * pStride * 4, 256);
+        const size_t offInfo = offUnits + round_up((size_t)nb * maxSeg * sizeof(DxUnit), 256), offRec = offInfo + round_up((size_t)nb * sizeof(DxInfo), 256);
+        const size_t need = offRec + round_up((size_t)nb * 16, 256);
+        if (c->dxPending && c->dxStream != s) HIPCHK(c, hipStreamWaitEvent(s, c->dxDone, 0));
+        if (need > c->dxBytes) {
+            if (c->dxPending) HIPCHK(c, hipEventSynchronize(c->dxDone));
+            if (c->d_dx) hipFree(c->d_dx);
+            c->d_dx = nullptr; c->dxBytes = 0;
+            if (hipMalloc((void**)&c->d_dx, need) != hipSuccess) { (void)hipGetLastError(); c->d_dx = nullptr; dx = false; }   // no room: one wave per block
+            else c->dxBytes = need;
+        }
+        if (dx) {
+            a.dxT = (uint64_t*)c->d_dx; a.dxTStride = (int64_t)tStride;
+            a.dxPtr = (uint32_t*)(c->d_dx + offPtr); a.dxPtrStride = (int64_t)pStride;
+            a.dxUnits = (DxUnit*)(c->d_dx + offUnits); a.dxMaxSeg = maxSeg;
+            a.dxInfo = (DxInfo*)(c->d_dx + offInfo);
+            const bool hashed = records && a.blockChecksum;
+            if (records) {
+                int64_t* so = (int64_t*)(c->d_dx + offRec); int32_t* ln = (int32_t*)(so + nb);
+                hipLaunchKernelGGL(k_dx_rec_prep, dim3((nb + 255) / 256), dim3(256), 0, s, a, so, ln);
+                a.dxSrcOff = so; a.dxLen = ln;
+                if (hashed) {
+                    a.dxHashBad = ln + nb;
+                    if (!c->dxHashStream) HIPCHK(c, hipStreamCreateWithFlags(&c->dxHashStream, hipStreamNonBlocking));
+                    if (!c->evDxFork) HIPCHK(c, hipEventCreateWithFlags(&c->evDxFork, hipEventDisableTiming));
+                    if (!c->evDxHash) HIPCHK(c, hipEventCreateWithFlags(&c->evDxHash, hipEventDisableTiming));
+                    HIPCHK(c, hipEventRecord(c->evDxFork, s));
+                    HIPCHK(c, hipStreamWaitEvent(c->dxHashStream, c->evDxFork, 0));
+                    hipLaunchKernelGGL(k_dx_rec_hash, dim3(nb), dim3(64), 0, c->dxHashStream, a);
+                    HIPCHK(c, hipEventRecord(c->evDxHash, c->dxHashStream));
+                }
+            }
+            const int chunks = (int)((outB + 1023) / 1024);
+            hipLaunchKernelGGL(k_dx_tables, dim3(maxSeg, nb), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(k_dx_stitch, dim3(nb), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(k_dx_fill, dim3(maxSeg, nb), dim3(64), 0, s, a);
+            for (int r = 0; r < kDxRounds; ++r) { a.dxRound = r; hipLaunchKernelGGL(k_dx_jump, dim3(chunks, nb), dim3(256), 0, s, a); }
+            if (hashed) HIPCHK(c, hipStreamWaitEvent(s, c->evDxHash, 0));
+            hipLaunchKernelGGL(k_dx_gather, dim3(chunks, nb), dim3(256), 0, s, a);
+            HIPCHK(c, hipGetLastError());
+        }
+    }
+    a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+    if (records) hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
+    else         hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
+    HIPCHK(c, hipGetLastError());
+    if (dx) {
+        if (!c->dxDone) HIPCHK(c, hipEventCreateWithFlags(&c->dxDone, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->dxDone, s));
+        c->dxPending = true; c->dxStream = s;
+    }
+    return PLZ4HIP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1894,6 +2091,8 @@ int plz4hip_ctx_trim(plz4hip_ctx* c)
     if (c->l1.d) { hipFree(c->l1.d); c->l1.d = nullptr; c->l1.bytes = 0; }
     if (c->d_hc) { hipFree(c->d_hc); c->d_hc = nullptr; c->hcWaves = 0; }
     if (c->d_h12) { hipFree(c->d_h12); c->d_h12 = nullptr; c->h12Bytes = 0; }
+    if (c->dxPending) { HIPCHK(c, hipEventSynchronize(c->dxDone)); c->dxPending = false; }
+    if (c->d_dx) { hipFree(c->d_dx); c->d_dx = nullptr; c->dxBytes = 0; }
     return PLZ4HIP_OK;
 }
 
@@ -1960,15 +2159,13 @@ int plz4hip_dev_decompress(plz4hip_ctx* c, int nBlocks, const void* src, int64_t
     std::lock_guard<std::mutex> g(c->mu);
     ENTER_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
     CodecArgs a{};
     a.src = (const uint8_t*)src; a.srcStride = srcStride; a.srcLen = srcLen;
     a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCap = dstCap;
-    a.result = result; a.queue = q; a.nBlocks = nBlocks;
+    a.result = result; a.nBlocks = nBlocks;
     a.dictLen = -1; a.prevTailLen = -1;
-    hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
-    HIPCHK(c, hipGetLastError());
-    return PLZ4HIP_OK;
+    // (the lengths live on the device: the strides bound them)
+    return launch_decode(c, s, a, nBlocks, nBlocks > 1 ? srcStride : (int64_t)(6 << 20), nBlocks > 1 ? dstStride : (int64_t)kDxMaxOut, false);
 }
 
 int plz4hip_dev_encode_records(plz4hip_ctx* c, const void* src, int64_t srcBytes, int bsz, int level,
@@ -2039,15 +2236,12 @@ int plz4hip_dev_decode_records(plz4hip_ctx* c, const void* body, const int64_t* 
     std::lock_guard<std::mutex> g(c->mu);
     ENTER_DEVICE(c);
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e; uint32_t* q = next_queue(c, s, &e); HIPCHK(c, e);
     CodecArgs a{};
     a.src = (const uint8_t*)body; a.recOff = recOff; a.bsz = bsz;
     a.dst = (uint8_t*)dst; a.dstStride = dstStride; a.dstCapAll = dstCap;
-    a.result = result; a.status = status; a.queue = q; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
+    a.result = result; a.status = status; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
     a.dictLen = -1; a.prevTailLen = -1;
-    hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nBlocks, c->decWaves)), dim3(64), 0, s, a);
-    HIPCHK(c, hipGetLastError());
-    return PLZ4HIP_OK;
+    return launch_decode(c, s, a, nBlocks, bsz, dstCap, true);
 }
 
 int plz4hip_dev_duplex_records(plz4hip_ctx* c, const void* src, int64_t srcBytes, int bsz, int blockChecksum, void* stage, int32_t* recLen,
@@ -2230,7 +2424,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
                 else if (dictMode) ENC_LAUNCH(k_encode_raw_dict, nb, c, s, a);
                 else { if (int rc = launch_l1(c, s, a, nb, maxIn, 1, &sl.l1)) return rc; } break;
         case 1: if (dictMode) hipLaunchKernelGGL(k_decode_raw_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
-                else hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a); break;
+                else { if (int rc = launch_decode(c, s, a, nb, maxIn, maxOut, false)) return rc; } break;
         case 2: a.dstCap = nullptr;
                 if (hcMode) { if (int rc = launch_hc(c, s, a, nb, maxIn, 0)) return rc; }
                 else if (dictMode) ENC_LAUNCH(k_encode_rec_dict, nb, c, s, a);
@@ -2238,7 +2432,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         case 3: a.dstCap = nullptr;
                 if (dictMode && dj->linked) hipLaunchKernelGGL(k_decode_rec_linked, dim3(grid_for(nCh, c->decWaves)), dim3(64), 0, s, a);
                 else if (dictMode) hipLaunchKernelGGL(k_decode_rec_dict, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
-                else hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a); break;
+                else { if (int rc = launch_decode(c, s, a, nb, bsz, bsz + 8, true)) return rc; } break;
         case 4: hipLaunchKernelGGL(k_xxh32, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s,
                                    (const uint8_t*)a.src, a.srcStride, a.srcLen, (uint32_t*)a.result, nb, q); break;
         }

@@ -417,6 +417,54 @@ extern "C" int emu_compress_hc_mid_ext(const uint8_t* src, int n, uint8_t* dst, 
     return r;
 }
 
+// ---- the few-block decoder (lz4_dx_device.inl) as the kernels run it: tables per input segment, stitch, pointer fill per unit,
+// jump rounds, gather.  Returns the decoded size; -999999: the block is left to the one-wave decoder (any anomaly); -888888: the
+// units disagree about where they meet (a bug).
+#include "../../plz4_amd/csrc/lz4_dx_device.inl"
+extern "C" int emu_dx_decode(const uint8_t* src, int n, uint8_t* dst, int cap, int* roundsOut)
+{
+    using namespace plz4;
+    if (roundsOut) *roundsOut = 0;
+    uint8_t* in = (uint8_t*)calloc((size_t)(n > 0 ? n : 0) + 64, 1);
+    if (n > 0) memcpy(in, src, (size_t)n);
+    const int nseg = dx_segments(n), jt = dx_tail_from(nseg);
+    uint64_t* T = (uint64_t*)calloc((size_t)(n > 0 ? n : 1) + 64, 8);
+    DxUnit* units = (DxUnit*)calloc((size_t)nseg + 1, sizeof(DxUnit));
+    const int capw = cap > 0 ? cap : 1;
+    uint32_t* ptr = (uint32_t*)malloc(((size_t)capw + 64) * 4);
+    for (int p = 0; p < capw + 64; ++p) ptr[p] = (uint32_t)p;
+    int result = -999999;
+    for (int j = nseg - 1; j >= 0; --j) dx_segment_table(in, n, j, T);                  // (any order: segments are independent)
+    if (dx_stitch(in, n, cap, T, units, nseg) == 0) {
+        bool bad = false; int64_t outLen = -1;
+        for (int j = jt; j >= 0 && !bad; --j) {
+            if (j < jt && units[j].ip < 0) continue;
+            const int64_t r = wave_dx_fill(in, n, dst, cap, ptr, units[j].ip, units[j].op, units[j].stop, j == jt);
+            if (r < 0) { bad = true; break; }
+            if (j == jt) outLen = r;
+            else {                                                                   // where this unit stops is where the next one starts
+                int k = j + 1; while (k < jt && units[k].ip < 0) ++k;
+                if (units[k].op != (int)r) { result = -888888; bad = true; }
+            }
+        }
+        if (!bad) {
+            int rounds = 0;
+            for (; rounds < kDxRounds; ++rounds) {
+                bool moved = false;
+                // (from the top down: a pointer never sees one that was already moved in this round -- the slowest the kernel's
+                // unordered workgroups can be)
+                for (int p0 = (((int)outLen - 1) / 256) * 256; p0 >= 0; p0 -= 256) moved |= dx_jump(ptr, p0, (int)outLen);
+                if (!moved) break;
+            }
+            if (roundsOut) *roundsOut = rounds;
+            for (int p0 = 0; p0 < (int)outLen; p0 += 256) dx_gather(dst, ptr, p0, (int)outLen);
+            result = (int)outLen;
+        }
+    }
+    free(in); free(T); free(units); free(ptr);
+    return result;
+}
+
 // diagnostics of the level-1 parser's pipeline (see plz4_emu_cnt in lz4_seq_device.inl); reset on read
 extern "C" void emu_parse_counters(unsigned long long* out8)
 {

@@ -12,7 +12,7 @@ from orclib import ROOT, _ptr, u8p
 
 EMU_SRC = os.path.join(ROOT, "tests", "emu", "emu_kernels.cpp")
 EMU_SO = os.path.join(ROOT, "tests", "emu", "_build", "libemu.so")
-DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_device.inl", "lz4_seq_device.inl", "lz4hc_device.inl", "lz4hc12_device.inl", "lz4hc_lazy_device.inl", "wave.h")]
+DEV_SRCS = [os.path.join(ROOT, "plz4_amd", "csrc", f) for f in ("lz4_dx_device.inl", "lz4_device.inl", "lz4_seq_device.inl", "lz4hc_device.inl", "lz4hc12_device.inl", "lz4hc_lazy_device.inl", "wave.h")]
 
 
 def build_emu():
@@ -96,6 +96,16 @@ class Emu:
         dst = np.zeros(max(cap, 1) + 32, dtype=np.uint8)
         r = int(self.L.emu_decode_block(_ptr(src), src.size, _ptr(dst), cap))
         return r, dst[:max(r, 0)]
+
+    def dx_decode(self, src: np.ndarray, cap: int):
+        """The few-block decoder (lz4_dx_device.inl) stage by stage as the kernels run it.  Returns (size, output, jump rounds);
+        size -999999: the block is left to the one-wave decoder."""
+        self.L.emu_dx_decode.restype = C.c_int
+        self.L.emu_dx_decode.argtypes = [u8p, C.c_int, u8p, C.c_int, C.POINTER(C.c_int)]
+        dst = np.zeros(max(cap, 1) + 64, dtype=np.uint8)
+        rounds = C.c_int(0)
+        r = int(self.L.emu_dx_decode(_ptr(src) if src.size else C.cast(None, u8p), src.size, _ptr(dst), cap, C.byref(rounds)))
+        return r, dst[:max(r, 0)], rounds.value
 
     def xxh32(self, a: np.ndarray) -> int:
         return int(self.L.emu_xxh32(_ptr(a) if a.size else C.cast(None, u8p), a.size))
