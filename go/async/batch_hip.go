@@ -33,14 +33,30 @@ import (
 
 const gatherWait = 200 * time.Microsecond
 
+// A batch below this many blocks goes block by block through the CPU compressor: the level-1 ENCODER is one wavefront per block
+// (89 ms per 4 MiB block whatever the batch), so through host memory the engine only draws level with the host's cores at about a
+// thousand blocks per call (DESIGN.md 6.0).  The batch can never exceed the writer's window -- cap(semChan) = opts.CalcPending(),
+// NParallel by default (opts/opts.go:62-95) -- so a deployment that wants the GPU on the write side sets WithPendingSize (or
+// NParallel) to a few thousand blocks; with default options this build compresses on the host, by design.  The READ side has a
+// few-block path since round 4 (one 4 MiB block in 1.4 ms, 16 in 9.8 ms through host memory; DESIGN.md 3.9) and its own, lower
+// threshold.
 func hipMinBatch() int {
 	if v, err := strconv.Atoi(os.Getenv("PLZ4_HIP_MIN_BATCH")); err == nil && v >= 1 {
 		return v
 	}
 	return 256
 }
+func hipMinReadBatch() int {
+	if v, err := strconv.Atoi(os.Getenv("PLZ4_HIP_MIN_READ_BATCH")); err == nil && v >= 1 {
+		return v
+	}
+	return 32 // (below that the host's cores decode a handful of blocks faster than the copies to and from the device take)
+}
 
 // gather: the first block is waited for; more are taken while they keep coming, up to max.  closed: inChan was closed.
+// full() says that the producer cannot admit another block (its semaphore is at capacity): then nothing more will arrive once
+// inChan is drained, so the blocks already queued are taken first and the wait is skipped -- checking full() before looking
+// at the channel would strand every admitted block but the first in batches of one.
 func gatherIn(in <-chan inBlkT, max int, full func() bool) (batch []inBlkT, closed bool) {
 	first, ok := <-in
 	if !ok {
@@ -49,17 +65,32 @@ func gatherIn(in <-chan inBlkT, max int, full func() bool) (batch []inBlkT, clos
 	batch = append(batch, first)
 	t := time.NewTimer(gatherWait)
 	defer t.Stop()
-	for len(batch) < max && !full() {
+	for len(batch) < max {
+		select { // what is queued already
+		case b, ok := <-in:
+			if !ok {
+				return batch, true
+			}
+			batch = append(batch, b)
+			continue
+		default:
+		}
+		if full() {
+			return batch, false
+		}
+		if !t.Stop() {
+			select {
+			case <-t.C:
+			default:
+			}
+		}
+		t.Reset(gatherWait)
 		select {
 		case b, ok := <-in:
 			if !ok {
 				return batch, true
 			}
 			batch = append(batch, b)
-			if !t.Stop() {
-				<-t.C
-			}
-			t.Reset(gatherWait)
 		case <-t.C:
 			return batch, false
 		}
@@ -152,7 +183,7 @@ func (w *asyncWriterT) compressLoop() {
 func (r *asyncRdrT) _decompressLoop() {
 	var (
 		bd, _    = r.dc.(compress.BatchDecompressorRaw)
-		minBatch = hipMinBatch()
+		minBatch = hipMinReadBatch()
 	)
 	one := func(srcBlk inBlkT) bool {
 		dstBlk, err := srcBlk.blk.Decompress(r.dc)

@@ -619,6 +619,12 @@ struct Hc12NoHook { DEVM bool operator()(int, int, int) const { return false; } 
 //                 or behind ipStop, its sequences as records in seqOut (lz4_seq_device.inl's format); hook(q, anchor, records)
 //                 is called when a window's first match has been found at q and may end the walk there; *run = how it ended.
 //                 The state at the top of the loop is (ip, anchor): the literal run in front of a window enters its prices.
+#if defined(PLZ4_EMU)
+static uint8_t* plz4_emu_f_need = nullptr;       // test diagnostics: the positions whose search result the parser actually used
+#define EMU_F_NEED(p) do { if (plz4_emu_f_need) plz4_emu_f_need[(p)] = 1; } while (0)
+#else
+#define EMU_F_NEED(p) do {} while (0)
+#endif
 template <bool kRec, class Hook>
 DEV int hc12_walk(const uint8_t* __restrict__ src, const int n, uint8_t* __restrict__ dst, const int cap,
                   const Hc12F* __restrict__ F, const uint16_t* __restrict__ chain, const Hc12Ws& w,
@@ -753,6 +759,9 @@ DEV int hc12_walk(const uint8_t* __restrict__ src, const int n, uint8_t* __restr
             const int ipL = ip, fb = fBase;
             any = BALLOT(fb + LANE >= ipL && fb + LANE <= mflimit && fLen[I_] != 0);
         }
+#if defined(PLZ4_EMU)
+        { const int to = any ? fBase + ctz64(any) : min_(fBase + 63, mflimit); for (int q_ = ip; q_ <= to; ++q_) EMU_F_NEED(q_); }
+#endif
         if (!any) { ip = fBase + 64; continue; }
         ip = fBase + ctz64(any);
         Hc12F first; first.len = RL(fLen, ip - fBase); first.off = RL(fOff, ip - fBase);
@@ -814,6 +823,7 @@ DEV int hc12_walk(const uint8_t* __restrict__ src, const int n, uint8_t* __restr
             if (!need) { cur = fBase + 64 - ip; continue; }
             const int s = ctz64(need);
             const int c = fBase + s - ip;
+            EMU_F_NEED(fBase + s);
             Hc12F nm; nm.len = RL(fLen, s); nm.off = RL(fOff, s);
             if (nm.len == kHc12NotComputed) { nm = search_now(ip + c); if (!nm.len) { cur = c + 1; continue; } }
             if (nm.len > kHc12Sufficient || nm.len + c >= kHcOptNum) {                     // :1948-1956

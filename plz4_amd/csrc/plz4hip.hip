@@ -1464,7 +1464,9 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl, bool lazy, bo
 // (blocks of 8 MiB and more -- raw block API only -- keep the one-thread-per-block kernel: the writer packs positions into 23 bits)
 bool use_h12(const CodecArgs& a, int maxLen) { return a.level >= 12 && !a.hcEx && maxLen < (1 << 23) && getenv("PLZ4HIP_HC12_OFF") == nullptr; }
 // levels 3..11, independent blocks up to 4 MiB: segments walked at once, stitched, record emit (lz4hc_lazy_device.inl)
-bool use_lazy(const CodecArgs& a, int maxLen) { return a.level >= 3 && a.level <= 11 && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_LAZY_OFF") == nullptr; }
+// (PLZ4HIP_HC12_LAZY=1, an experiment switch: level 12 on the same walk -- its searches made where the optimal parser asks for them,
+// wave-wide, instead of every position's search up front, lz4hc12_device.inl)
+bool use_lazy(const CodecArgs& a, int maxLen) { return a.level >= 3 && (a.level <= 11 || getenv("PLZ4HIP_HC12_LAZY") != nullptr) && !a.hcEx && maxLen > 0 && maxLen <= kSeqMaxBlock && getenv("PLZ4HIP_HC_LAZY_OFF") == nullptr; }
 
 int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, int rawMode, plz4hip_ctx::L1Ws* ws, bool* midDeclined = nullptr,
               const CodecArgs* rider = nullptr);

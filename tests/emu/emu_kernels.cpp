@@ -261,6 +261,19 @@ extern "C" int emu_compress_hc12(const uint8_t* src, int n, uint8_t* dst, int ca
     return r;
 }
 
+// diagnostics: which positions' search results does the level-12 parser use?  need[n] <- 1 for those (one walk over the block)
+extern "C" int emu_hc12_need(const uint8_t* src, int n, uint8_t* need)
+{
+    using namespace plz4;
+    memset(need, 0, (size_t)n);
+    plz4_emu_f_need = need;
+    uint8_t* dst = (uint8_t*)malloc((size_t)n + n / 255 + 64);
+    const int r = emu_compress_hc12(src, n, dst, n + n / 255 + 16, 0, 1024, 0, 8192);
+    free(dst);
+    plz4_emu_f_need = nullptr;
+    return r;
+}
+
 // The search as the kernel runs it (Hc12Walk: lists, phases) against the plain chain walk (Hc12Lane), every position of the
 // block: returns the number of positions whose answers differ.  trips (optional, 10 counters): phase trips in all.
 extern "C" int emu_hc12_search_check(const uint8_t* src, int n, long* trips)
