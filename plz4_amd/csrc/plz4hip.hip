@@ -1042,10 +1042,13 @@ __global__ __launch_bounds__(64) void k_decode_raw(CodecArgs a)
 
 // FrameReader._read's per-block checks + BlkT.Decompress on the device (blk/frame.go:54-127, blk.go:50-61).
 // Record i starts at src + recOff[i] when recOff is given, else at src + i*srcStride with srcLen[i] bytes.
+// kDx: behind the few-block path (launch_decode): only the records that path has flagged.  A template parameter so that the
+// kernels of the bulk path -- k_decode_rec, k_l1_duplex: bound by their scalar registers -- do not carry the test.
+template <bool kDx = false>
 __device__ __forceinline__ void decode_rec_loop(const CodecArgs& a, uint8_t* dl)
 {
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
-        if (a.dxInfo && !a.dxInfo[i].bad) continue;                          // (answered by the few-block path)
+        if (kDx && !a.dxInfo[i].bad) continue;                               // (answered by the few-block path)
         const uint8_t* rec    = a.recOff ? a.src + a.recOff[i] : a.src + (int64_t)i * a.srcStride;
         const int64_t  recLen = a.recOff ? a.recOff[i + 1] - a.recOff[i] : (int64_t)a.srcLen[i];
         uint8_t*       out    = a.dst + (int64_t)i * a.dstStride;
@@ -1076,7 +1079,12 @@ __device__ __forceinline__ void decode_rec_loop(const CodecArgs& a, uint8_t* dl)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_decode_rec(CodecArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t dl[kDecLdsBytes];       // the vector path assembles each batch's output here
-    decode_rec_loop(a, dl);
+    decode_rec_loop<false>(a, dl);
+}
+__global__ __launch_bounds__(64) void k_decode_rec_dx(CodecArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t dl[kDecLdsBytes];
+    decode_rec_loop<true>(a, dl);
 }
 
 // The level-1 parse of one call and the record decode of another in ONE launch (plz4hip_dev_duplex_records).  The parser is a
@@ -1105,7 +1113,7 @@ void k_l1_duplex(CodecArgs a, CodecArgs d)
         if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
         l1_parse_loop(a, tabS[w]);
     } else {
-        decode_rec_loop(d, dlS[w - P]);
+        decode_rec_loop<false>(d, dlS[w - P]);
     }
 }
 
@@ -1496,7 +1504,6 @@ int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLe
     if (c->dxPending) hipEventSynchronize(c->dxDone);
     if (c->d_dx) hipFree(c->d_dx);
     if (c->dxDone) hipEventDestroy(c->dxDone);
-    if (c->dxHashStream) { hipStreamSynchronize(c->dxHashStream); hipStreamDestroy(c->dxHashStream); }
     if (c->evDxFork) hipEventDestroy(c->evDxFork);
     if (c->evDxHash) hipEventDestroy(c->evDxHash);
             c->d_hcPfx = nullptr; c->hcPfxCap = 0;
@@ -1954,7 +1961,10 @@ int launch_decode(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int64_t ma
                 a.dxSrcOff = so; a.dxLen = ln;
                 if (hashed) {
                     a.dxHashBad = ln + nb;
-                    if (!c->dxHashStream) HIPCHK(c, hipStreamCreateWithFlags(&c->dxHashStream, hipStreamNonBlocking));
+                    // (the ctx's own stream, idle otherwise: one stream more would push the staging slots' streams onto shared
+                    // hardware queues -- the runtime has four -- and cost the large host calls their overlap: 412 -> 610 ms per
+                    // 2304 blocks, measured)
+                    c->dxHashStream = c->stream;
                     if (!c->evDxFork) HIPCHK(c, hipEventCreateWithFlags(&c->evDxFork, hipEventDisableTiming));
                     if (!c->evDxHash) HIPCHK(c, hipEventCreateWithFlags(&c->evDxHash, hipEventDisableTiming));
                     HIPCHK(c, hipEventRecord(c->evDxFork, s));
@@ -1974,8 +1984,9 @@ int launch_decode(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int64_t ma
         }
     }
     a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-    if (records) hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
-    else         hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
+    if (records && dx) hipLaunchKernelGGL(k_decode_rec_dx, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
+    else if (records)  hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
+    else               hipLaunchKernelGGL(k_decode_raw, dim3(grid_for(nb, c->decWaves)), dim3(64), 0, s, a);
     HIPCHK(c, hipGetLastError());
     if (dx) {
         if (!c->dxDone) HIPCHK(c, hipEventCreateWithFlags(&c->dxDone, hipEventDisableTiming));
