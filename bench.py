@@ -9,8 +9,9 @@ the dominant kernel and plz4's CPU path timed beside it.
 One step = one pass of the hot path, both directions, over one batch that is already resident in HBM:
     ONE duplex call (plz4hip_dev_duplex_records): the level-1 encode of this step's B blocks (-> staged records + xxh32)
     and, in the same launch, the decode of the frame body the previous step produced (-> B plaintext blocks, checksums
-    verified) -- a writer's next batch beside a reader's;  -> scan + compaction of the new records into the frame body
-    [N > 1: RCCL gather of the bodies to rank 0 + interleave into the final frame body].
+    verified) -- a writer's next batch beside a reader's; the records land back to back in the frame body (plz4hip_dev_duplex_body:
+    no staging area, no compaction pass since round 4)  [N > 1: RCCL gather of the bodies to rank 0 + interleave into the final
+    frame body, or --gather none].
 Every step is one full encode and one full decode of B blocks; the body the last step produced is decoded and compared
 after the timed region.  `--duplex 0` (and every HC level) runs the step as encode -> frame body -> decode of the same
 batch, one call after the other; at N = 1 the default run times those K steps as well and reports them as `serial_step`.
@@ -216,15 +217,15 @@ def crossover(args):
 
 def memory_plan(B: int, world: int, gather_rank0: bool, duplex: bool, ratio: float, level: int = 1):
     """GiB this bench holds on the busiest rank (rank 0) for B blocks per GPU: its own buffers, the library's level-1 workspace
-    (8 bytes per possible sequence -- a sequence takes at least 4 input bytes -- plus the chunk tables: launch_l1 in plz4hip.hip) and,
+    (9 bytes per possible sequence -- a sequence takes at least 4 input bytes -- plus the chunk tables: launch_l1 in plz4hip.hip) and,
     when the framed output is gathered, the assembled frame body and the receive pieces (plz4_amd/shard.py)."""
     S = B * BSZ
     C = ratio * S
     g = 2.0**30
     plan = {
-        "src": S / g, "out": S / g, "stage": B * (BSZ + 16) / g,
+        "src": S / g, "out": S / g, "stage": (B * (BSZ + 16) / g) if level > 2 else 0.0,
         "frame_body": min(B * (BSZ + 8), C * 1.02 + (1 << 20)) / g * (2 if duplex else 1),
-        "l1_workspace": (B * ((BSZ // 4 + 3 + 63) // 64 * 64) * 8 + B * 1024 * 8) / g if level == 1 else 0.0,
+        "l1_workspace": (B * ((BSZ // 4 + 3 + 63) // 64 * 64) * 9 + B * 1024 * 8) / g if level <= 2 else 0.0,
     }
     if gather_rank0 and world > 1:
         plan["gathered_frame"] = world * C / g
@@ -341,7 +342,8 @@ def main():
         parts.append({
             "b0": b0, "nb": nb, "bytes": nb * BSZ,
             "src": d_src[b0 * BSZ:b1 * BSZ], "out": d_out[b0 * BSZ:b1 * BSZ],
-            "stage": torch.empty(nb * stride, dtype=torch.uint8, device=dev),
+            # (levels 1 and 2 write their records straight into the frame body: plz4hip_dev_encode_body / _duplex_body)
+            "stage": torch.empty(nb * stride, dtype=torch.uint8, device=dev) if args.level > 2 else None,
             "len": torch.zeros(nb, dtype=torch.int32, device=dev),
             "off": torch.zeros(nb + 1, dtype=torch.int64, device=dev),
             # the frame body is sized for the data at hand, not for the worst case (24 GiB per 6144 blocks): 0.55 of the plaintext
@@ -357,6 +359,7 @@ def main():
         pt["bodies"] = [pt["body"], None]                                    # (the second one once the gate has told how large a body is)
         pt["offs"] = [pt["off"], torch.zeros_like(pt["off"])]
         pt["cur"] = 0
+        pt["gat_ev"] = [None, None]                                          # N > 1: the exchange that last read each body
     s_enc = torch.cuda.current_stream()
     s_dec = torch.cuda.Stream(device=dev) if NP > 1 else s_enc
     # N > 1: the framed-output gather (RCCL send/recv + the interleave on rank 0) runs on its own stream, next to the decode
@@ -389,20 +392,21 @@ def main():
             if e: e[5].record(s_enc)
 
     def step_duplex(ev=None):
-        """one duplex call: encode of this step's batch + decode of the previous step's frame body; then scan + compact"""
+        """one duplex call: encode of this step's batch straight into a frame body + decode of the previous step's frame body"""
         gather["live"] = []
         pt = parts[0]
         e = ev[0] if ev else None
         prv = pt["cur"]; cur = 1 - prv
         if e: e[0].record(s_enc)
-        eng.dev_duplex_records(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["stage"].data_ptr(), pt["len"].data_ptr(),
-                               pt["bodies"][prv].data_ptr(), pt["offs"][prv].data_ptr(), pt["nb"], BSZ, True,
-                               pt["out"].data_ptr(), BSZ, BSZ, pt["res"].data_ptr(), pt["st"].data_ptr(), s_enc.cuda_stream)
+        # (two bodies alternate: the one this call writes is the one the exchange of the step BEFORE LAST read -- that exchange has
+        # to be over; the last step's, which reads the body this call decodes, runs on under this call)
+        if s_gat is not None and pt["gat_ev"][cur] is not None:
+            s_enc.wait_event(pt["gat_ev"][cur])
+        eng.dev_duplex_body(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["bodies"][cur].data_ptr(), pt["bodies"][cur].numel(),
+                            pt["offs"][cur].data_ptr(), pt["len"].data_ptr(),
+                            pt["bodies"][prv].data_ptr(), pt["offs"][prv].data_ptr(), pt["nb"], BSZ, True,
+                            pt["out"].data_ptr(), BSZ, BSZ, pt["res"].data_ptr(), pt["st"].data_ptr(), s_enc.cuda_stream)
         if e: e[1].record(s_enc)
-        if s_gat is not None:
-            s_enc.wait_stream(s_gat)
-        eng.dev_compact_records(pt["stage"].data_ptr(), stride, pt["len"].data_ptr(), pt["nb"], pt["offs"][cur].data_ptr(),
-                                pt["bodies"][cur].data_ptr(), pt["bodies"][cur].numel(), s_enc.cuda_stream)
         pt["cur"] = cur; pt["body"] = pt["bodies"][cur]; pt["off"] = pt["offs"][cur]
         packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
         packed.record(s_enc)
@@ -411,6 +415,7 @@ def main():
             with torch.cuda.stream(s_gat):
                 frame_gather(pt)
                 if e: e[3].record(s_gat)
+                pt["gat_ev"][cur] = torch.cuda.Event(); pt["gat_ev"][cur].record(s_gat)
         elif e:
             e[3].record(s_enc)
         if e: e[4].record(s_enc); e[5].record(s_enc)
@@ -425,13 +430,20 @@ def main():
         for i, pt in enumerate(parts):
             e = ev[i] if ev else None
             if e: e[0].record(s_enc)
-            eng.dev_encode_records(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["stage"].data_ptr(), pt["len"].data_ptr(), s_enc.cuda_stream,
-                                   level=args.level)
-            if e: e[1].record(s_enc)
-            if s_gat is not None:
-                s_enc.wait_stream(s_gat)                       # the previous step's sends (and interleave) still read this body
-            eng.dev_compact_records(pt["stage"].data_ptr(), stride, pt["len"].data_ptr(), pt["nb"], pt["off"].data_ptr(),
-                                    pt["body"].data_ptr(), pt["body"].numel(), s_enc.cuda_stream)
+            if args.level <= 2:
+                if s_gat is not None:
+                    s_enc.wait_stream(s_gat)                   # the previous step's sends (and interleave) still read this body
+                eng.dev_encode_body(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["body"].data_ptr(), pt["body"].numel(),
+                                    pt["off"].data_ptr(), pt["len"].data_ptr(), s_enc.cuda_stream, level=args.level)
+                if e: e[1].record(s_enc)
+            else:
+                eng.dev_encode_records(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["stage"].data_ptr(), pt["len"].data_ptr(), s_enc.cuda_stream,
+                                       level=args.level)
+                if e: e[1].record(s_enc)
+                if s_gat is not None:
+                    s_enc.wait_stream(s_gat)                   # the previous step's sends (and interleave) still read this body
+                eng.dev_compact_records(pt["stage"].data_ptr(), stride, pt["len"].data_ptr(), pt["nb"], pt["off"].data_ptr(),
+                                        pt["body"].data_ptr(), pt["body"].numel(), s_enc.cuda_stream)
             packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
             packed.record(s_enc)
             if gather_rank0:

@@ -229,6 +229,21 @@ int plz4hip_dev_duplex_records(plz4hip_ctx* ctx, const void* src, int64_t srcByt
                                const void* body, const int64_t* recOff, int nDecBlocks, int decBsz, int decBlockChecksum,
                                void* dst, int64_t dstStride, int dstCap, int32_t* result, int32_t* status, void* stream);
 
+/* plz4hip_dev_encode_body: plz4hip_dev_encode_records + plz4hip_dev_compact_records in one call, without the staging area and
+ * without the second pass over the records -- blk.CompressToBlk (blk/blk.go:69-109) for every block and the writer's in-order
+ * emission (async/writer.go:284-381) as ONE contiguous frame body: record i lands at body + recOff[i], recOff[nBlocks] = the body's
+ * length, recLen[i] = record i's bytes (a negative PLZ4HIP_E_* for a block the engine failed on; it takes no room).  The emit stage
+ * knows every record's length before it writes a byte, so the records' places come from a scan between its passes.  Levels 1
+ * and 2, blocks up to 4 MiB (the staged call; PLZ4HIP_E_NOMEM if its workspace cannot be had).  recOff[nBlocks] > bodyCap: the
+ * records beyond the room were not written.  plz4hip_dev_duplex_body: the same with the record decode of another batch in the
+ * same launch, as plz4hip_dev_duplex_records. */
+int plz4hip_dev_encode_body(plz4hip_ctx* ctx, const void* src, int64_t srcBytes, int bsz, int level, int blockChecksum,
+                            void* body, int64_t bodyCap, int64_t* recOff, int32_t* recLen, void* stream);
+int plz4hip_dev_duplex_body(plz4hip_ctx* ctx, const void* src, int64_t srcBytes, int bsz, int blockChecksum,
+                            void* body, int64_t bodyCap, int64_t* recOff, int32_t* recLen,
+                            const void* decBody, const int64_t* decRecOff, int nDecBlocks, int decBsz, int decBlockChecksum,
+                            void* dst, int64_t dstStride, int dstCap, int32_t* result, int32_t* status, void* stream);
+
 /* Raw LZ4 blocks on the device (no record framing): block i = src + i*srcStride (srcLen[i] bytes) ->
  * dst + i*dstStride (capacity dstCap[i]); result[i] as in A, levels 1..12.  srcLen/dstCap/result are device arrays.
  * maxLen is a host value the per-block workspaces are sized from, at EVERY level: it must be >= every srcLen[i]; a block whose

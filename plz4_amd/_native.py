@@ -18,7 +18,7 @@ SYMBOLS = [
     "plz4hip_last_error", "plz4hip_compress_bound", "plz4hip_compress_batch", "plz4hip_decompress_batch",
     "plz4hip_xxh32_batch", "plz4hip_encode_records", "plz4hip_decode_records", "plz4hip_dev_stage_stride",
     "plz4hip_dev_encode_records", "plz4hip_dev_compact_records", "plz4hip_dev_scatter_records",
-    "plz4hip_dev_decode_records", "plz4hip_dev_duplex_records", "plz4hip_dev_compress", "plz4hip_dev_decompress", "plz4hip_ctx_trim",
+    "plz4hip_dev_decode_records", "plz4hip_dev_duplex_records", "plz4hip_dev_encode_body", "plz4hip_dev_duplex_body", "plz4hip_dev_compress", "plz4hip_dev_decompress", "plz4hip_ctx_trim",
     "plz4hip_dev_resident_waves", "plz4hip_dict_create", "plz4hip_dict_destroy", "plz4hip_compress_batch_dict", "plz4hip_decode_records_chains",
     "plz4hip_decompress_batch_dict", "plz4hip_encode_records_ex", "plz4hip_decode_records_ex",
     "plz4hip_xxh32_stream_create", "plz4hip_xxh32_stream_destroy", "plz4hip_xxh32_stream_reset", "plz4hip_xxh32_stream_update",
@@ -91,6 +91,11 @@ def load():
     L.plz4hip_dev_duplex_records.restype = C.c_int
     L.plz4hip_dev_duplex_records.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp, vp,
                                              vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp, vp, vp]
+    L.plz4hip_dev_encode_body.restype = C.c_int
+    L.plz4hip_dev_encode_body.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp, vp]
+    L.plz4hip_dev_duplex_body.restype = C.c_int
+    L.plz4hip_dev_duplex_body.argtypes = [vp, vp, C.c_int64, C.c_int, C.c_int, vp, C.c_int64, vp, vp,
+                                          vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, C.c_int, vp, vp, vp]
     L.plz4hip_dev_compress.restype = C.c_int
     L.plz4hip_dev_compress.argtypes = [vp, C.c_int, vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int, C.c_int, vp, vp]
     L.plz4hip_dev_decompress.restype = C.c_int
@@ -339,6 +344,19 @@ class Engine:
         self._chk(self.L.plz4hip_dev_duplex_records(self.h, src_ptr, src_bytes, bsz, int(block_checksum), stage_ptr, reclen_ptr,
                                                     body_ptr, recoff_ptr, ndec, dec_bsz, int(dec_block_checksum), dst_ptr,
                                                     dst_stride, dst_cap, result_ptr, status_ptr, stream))
+
+    def dev_encode_body(self, src_ptr, src_bytes, bsz, block_checksum, body_ptr, body_cap, recoff_ptr, reclen_ptr, stream=0, level=1):
+        """records straight into the frame body: record i at body + recOff[i], recOff[n] = the body's length"""
+        self._chk(self.L.plz4hip_dev_encode_body(self.h, src_ptr, src_bytes, bsz, level, int(block_checksum), body_ptr, body_cap,
+                                                 recoff_ptr, reclen_ptr, stream))
+
+    def dev_duplex_body(self, src_ptr, src_bytes, bsz, block_checksum, body_ptr, body_cap, recoff_ptr, reclen_ptr,
+                        dec_body_ptr, dec_recoff_ptr, ndec, dec_bsz, dec_block_checksum, dst_ptr, dst_stride, dst_cap,
+                        result_ptr, status_ptr, stream=0):
+        """dev_encode_body of one batch and the record decode of another in one call (k_l1_duplex)"""
+        self._chk(self.L.plz4hip_dev_duplex_body(self.h, src_ptr, src_bytes, bsz, int(block_checksum), body_ptr, body_cap, recoff_ptr, reclen_ptr,
+                                                 dec_body_ptr, dec_recoff_ptr, ndec, dec_bsz, int(dec_block_checksum), dst_ptr,
+                                                 dst_stride, dst_cap, result_ptr, status_ptr, stream))
 
     def stage_stride(self, bsz: int) -> int:
         return int(self.L.plz4hip_dev_stage_stride(bsz))

@@ -83,6 +83,9 @@ struct CodecArgs {
     uint32_t*       dxPtr;      int64_t dxPtrStride;
     DxUnit*         dxUnits;    int dxMaxSeg;   int dxRound;
     DxInfo*         dxInfo;
+    // the staged level-1 call writing its records back to back (plz4hip_dev_encode_body): dst = the frame body, bodyOff[i] = where
+    // record i starts (made by the call: the scan over the records' lengths), bodyCap = the body's room
+    int64_t*        bodyOff;    int64_t bodyCap;
     const int64_t*  dxSrcOff;   const int32_t* dxLen;                       // records: where a block's payload starts in src and its size (-1: not this path's)
     int32_t*        dxHashBad;                                              // records: the payload's xxh32 does not match (k_dx_rec_hash)
 };
@@ -208,7 +211,11 @@ __global__ __launch_bounds__(256) void k_l1_scan(CodecArgs a)
         a.l1Info[i] = inf;
         if (broken) a.result[gi] = PLZ4HIP_E_DEVICE;
         else if (a.rawMode) a.result[gi] = total;
-        else {
+        else if (a.bodyOff) {
+            // records back to back: every record's length now (the scan behind this kernel places them; the size word is written
+            // with the payload, k_l1_write)
+            a.result[gi] = (total ? total : n) + 4 + (a.blockChecksum ? 4 : 0);
+        } else {
             const int c = total ? total : n;                                          // ErrCompress -> stored raw (blk.go:78-92)
             st32u(a.dst + (int64_t)gi * a.dstStride, total ? ((uint32_t)c & 0x7FFFFFFFu) : (0x80000000u | ((uint32_t)n & 0x7FFFFFFFu)));
             if (!a.blockChecksum) a.result[gi] = c + 4;
@@ -225,6 +232,14 @@ template <bool kBack> __global__ __launch_bounds__(256) void k_l1_write(CodecArg
     const int n  = block_len(a, gi);
     const uint8_t* s   = a.src + (int64_t)gi * a.srcStride;
     uint8_t*       out = a.dst + (int64_t)gi * a.dstStride + (a.rawMode ? 0 : 4);
+    if (a.bodyOff) {
+        // the record's place in the frame body; one that does not fit is not written (the caller sees bodyOff[n] > bodyCap)
+        const int64_t off = a.bodyOff[gi];
+        if (inf.nseq == kSeqEngineFailed || off + (int64_t)((inf.total ? inf.total : n) + 4 + (a.blockChecksum ? 4 : 0)) > a.bodyCap) return;
+        out = a.dst + off + 4;
+        if (wave == 0 && (threadIdx.x & 63u) == 0)                                    // the size word, stored iff the encoder returned 0 (blk.go:78-92)
+            st32u(out - 4, inf.total ? ((uint32_t)inf.total & 0x7FFFFFFFu) : (0x80000000u | ((uint32_t)n & 0x7FFFFFFFu)));
+    }
     if (inf.total > 0) {
         const uint64_t* seq = a.l1Seq + (int64_t)i * a.l1SeqStride;
         const int nChunks = (inf.nseq + kSeqChunk - 1) / kSeqChunk;
@@ -247,8 +262,13 @@ __global__ __launch_bounds__(256) void k_l1_finish(CodecArgs a)
     const SeqInfo inf = a.l1Info[i];
     const int c = inf.total ? inf.total : block_len(a, gi);
     uint8_t* rec = a.dst + (int64_t)gi * a.dstStride;
+    if (a.bodyOff) {
+        const int64_t off = a.bodyOff[gi];
+        if (inf.nseq == kSeqEngineFailed || off + (int64_t)c + 8 > a.bodyCap) return;     // (not written: k_l1_write)
+        rec = a.dst + off;
+    }
     const uint32_t x = wave_xxh32_staged(rec + 4, c, stagebuf[threadIdx.x >> 6]);
-    if ((threadIdx.x & 63u) == 0) { st32u(rec + 4 + c, x); a.result[gi] = inf.nseq == kSeqEngineFailed ? PLZ4HIP_E_DEVICE : c + 8; }
+    if ((threadIdx.x & 63u) == 0) { st32u(rec + 4 + c, x); if (!a.bodyOff) a.result[gi] = inf.nseq == kSeqEngineFailed ? PLZ4HIP_E_DEVICE : c + 8; }
 }
 
 // One level-1 block under a dictionary context and/or after another linked block.  Every input block of such a call has
@@ -1160,6 +1180,30 @@ __global__ __launch_bounds__(1024) void k_scan(const int32_t* __restrict__ len, 
     if (t == 1023) off[n] = part[1023];
 }
 
+// ... continued behind an earlier part: off[0] holds where this part starts (the total the scan of the part before left there);
+// lengths that are not positive (an engine failure code) count as 0
+__global__ __launch_bounds__(1024) void k_scan_from(const int32_t* __restrict__ len, int64_t* __restrict__ off, int n, int first)
+{
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(t * per, n), hi = min(lo + per, n);
+    const int64_t base = first ? 0 : off[0];
+    int64_t s = 0;
+    for (int i = lo; i < hi; ++i) s += len[i] > 0 ? len[i] : 0;
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int64_t v = (t >= d) ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int64_t run = base + part[t] - s;
+    for (int i = lo; i < hi; ++i) { off[i] = run; run += len[i] > 0 ? len[i] : 0; }
+    if (t == 1023) off[n] = base + part[1023];
+}
+
 // Bytes to hand back per block of a host call: the result if positive (sizes), nothing for 0 / error codes.
 // plz4hip_dev_compress: the lengths live on the device and the workspaces are sized from the caller's maxLen.  A private copy with
 // every length outside [0, maxLen] replaced by 0 is what the kernels see; such a block's result becomes PLZ4HIP_E_ARG afterwards.
@@ -1848,6 +1892,7 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             fprintf(stderr, "plz4hip: level 1, %d blocks of <= %d: free %zu MiB, workspace %zu MiB, groups of %d%s\n", nb, maxLen, freeB >> 20, ws->bytes >> 20, per, fused ? " (fused)" : "");
     }
     if (fused && mid) { *midDeclined = true; return PLZ4HIP_OK; }
+    if (fused && a.bodyOff) return fail(c, PLZ4HIP_E_NOMEM, "records straight into a frame body need the staged call's workspace (blocks up to 4 MiB)");
     if (fused) {
         a.queue = next_queue(c, s, &e); HIPCHK(c, e);
         if (rawMode) ENC_LAUNCH(k_encode_raw, nb, c, s, a); else ENC_LAUNCH(k_encode_rec, nb, c, s, a);
@@ -1907,6 +1952,7 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         if (mid) hipLaunchKernelGGL(k_l1_sizes<false>, dim3(wg, ng), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_l1_sizes<true>, dim3(wg, ng), dim3(256), 0, s, a);
         hipLaunchKernelGGL(k_l1_scan, dim3((ng + 3) / 4), dim3(256), 0, s, a);
+        if (a.bodyOff) hipLaunchKernelGGL(k_scan_from, dim3(1), dim3(1024), 0, s, (const int32_t*)(a.result + g0), a.bodyOff + g0, ng, g0 == 0 ? 1 : 0);
         if (mid) hipLaunchKernelGGL(k_l1_write<false>, dim3(wg, ng), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(k_l1_write<true>, dim3(wg, ng), dim3(256), 0, s, a);
         if (!rawMode && a.blockChecksum) hipLaunchKernelGGL(k_l1_finish, dim3((ng + 3) / 4), dim3(256), 0, s, a);
@@ -2286,6 +2332,64 @@ int plz4hip_dev_duplex_records(plz4hip_ctx* c, const void* src, int64_t srcBytes
     a.dst = (uint8_t*)stage; a.dstStride = plz4hip_dev_stage_stride(bsz);
     a.result = recLen; a.nBlocks = nBlocks; a.blockChecksum = blockChecksum;
     a.dictLen = -1; a.prevTailLen = -1;
+    return launch_l1(c, s, a, nBlocks, bsz, 0, nullptr, nullptr, nDecBlocks > 0 ? &d : nullptr);
+}
+
+// plz4hip_dev_encode_records + plz4hip_dev_compact_records in one: the records go straight to their place in the frame body
+// (the emit stage knows every record's length before it writes a byte: k_l1_scan, then a scan over the blocks).  No staging
+// area, no second pass over the records.  Level 1 and 2 (the staged call); recOff[nBlocks] > bodyCap: the records beyond the
+// room were not written.
+static int encode_body_args(plz4hip_ctx* c, CodecArgs& a, const void* src, int64_t srcBytes, int bsz, int blockChecksum,
+                            void* body, int64_t bodyCap, int64_t* recOff, int32_t* recLen, int* nBlocksOut, const char* who)
+{
+    if (!c || srcBytes < 0 || bsz <= 0 || bsz > kSeqMaxBlock || !body || bodyCap <= 0 || !recOff || !recLen) return fail(c, PLZ4HIP_E_ARG, who);
+    const int64_t nb64 = (srcBytes + bsz - 1) / bsz;
+    if (nb64 > 0x7FFFFFFF) return fail(c, PLZ4HIP_E_ARG, "too many blocks");
+    *nBlocksOut = (int)nb64;
+    a.src = (const uint8_t*)src; a.srcStride = bsz; a.srcBytes = srcBytes; a.bsz = bsz;
+    a.dst = (uint8_t*)body; a.dstStride = 0; a.bodyOff = recOff; a.bodyCap = bodyCap;
+    a.result = recLen; a.nBlocks = *nBlocksOut; a.blockChecksum = blockChecksum;
+    a.dictLen = -1; a.prevTailLen = -1;
+    return PLZ4HIP_OK;
+}
+int plz4hip_dev_encode_body(plz4hip_ctx* c, const void* src, int64_t srcBytes, int bsz, int level, int blockChecksum,
+                            void* body, int64_t bodyCap, int64_t* recOff, int32_t* recLen, void* stream)
+{
+    if (level != 1 && level != 2) return fail(c, PLZ4HIP_E_UNSUPPORTED, "plz4hip_dev_encode_body: levels 1 and 2 (the others: plz4hip_dev_encode_records + plz4hip_dev_compact_records)");
+    CodecArgs a{}; int nBlocks = 0;
+    if (int rc = encode_body_args(c, a, src, srcBytes, bsz, blockChecksum, body, bodyCap, recOff, recLen, &nBlocks, "plz4hip_dev_encode_body: bad argument")) return rc;
+    std::lock_guard<std::mutex> g(c->mu);
+    ENTER_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    if (nBlocks == 0) { HIPCHK(c, hipMemsetAsync(recOff, 0, sizeof(int64_t), s)); return PLZ4HIP_OK; }
+    if (level == 2) { a.level = 2; return launch_hc(c, s, a, nBlocks, bsz, 0); }
+    return launch_l1(c, s, a, nBlocks, bsz, 0, nullptr);
+}
+// ... and with the record decode of another batch in the same launch (plz4hip_dev_duplex_records' counterpart)
+int plz4hip_dev_duplex_body(plz4hip_ctx* c, const void* src, int64_t srcBytes, int bsz, int blockChecksum,
+                            void* body, int64_t bodyCap, int64_t* recOff, int32_t* recLen,
+                            const void* decBody, const int64_t* decRecOff, int nDecBlocks, int decBsz, int decBlockChecksum,
+                            void* dst, int64_t dstStride, int dstCap, int32_t* result, int32_t* status, void* stream)
+{
+    CodecArgs a{}; int nBlocks = 0;
+    if (int rc = encode_body_args(c, a, src, srcBytes, bsz, blockChecksum, body, bodyCap, recOff, recLen, &nBlocks, "plz4hip_dev_duplex_body: bad argument (encode side)")) return rc;
+    if (nDecBlocks < 0 || (nDecBlocks > 0 && (!decBody || !decRecOff || !dst || !result || !status || decBsz <= 0))) return fail(c, PLZ4HIP_E_ARG, "plz4hip_dev_duplex_body: bad argument (decode side)");
+    if (nBlocks == 0 && nDecBlocks == 0) return PLZ4HIP_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    ENTER_DEVICE(c);
+    hipStream_t s = (hipStream_t)stream;
+    CodecArgs d{};
+    d.src = (const uint8_t*)decBody; d.recOff = decRecOff; d.bsz = decBsz;
+    d.dst = (uint8_t*)dst; d.dstStride = dstStride; d.dstCapAll = dstCap;
+    d.result = result; d.status = status; d.nBlocks = nDecBlocks; d.blockChecksum = decBlockChecksum;
+    d.dictLen = -1; d.prevTailLen = -1;
+    if (nDecBlocks > 0) { hipError_t e; d.queue = next_queue(c, s, &e); HIPCHK(c, e); }
+    if (nBlocks == 0) {
+        HIPCHK(c, hipMemsetAsync(recOff, 0, sizeof(int64_t), s));
+        hipLaunchKernelGGL(k_decode_rec, dim3(grid_for(nDecBlocks, c->decWaves)), dim3(64), 0, s, d);
+        HIPCHK(c, hipGetLastError());
+        return PLZ4HIP_OK;
+    }
     return launch_l1(c, s, a, nBlocks, bsz, 0, nullptr, nullptr, nDecBlocks > 0 ? &d : nullptr);
 }
 

@@ -406,6 +406,69 @@ def test_gpu_duplex_call_on_a_chip_full_of_blocks(orc):
     e.close()
 
 
+@pytest.mark.parametrize("budget_mib,level", [(0, 1), (40, 1), (0, 2)])
+def test_gpu_records_straight_into_the_frame_body(orc, ref, monkeypatch, budget_mib, level):
+    """plz4hip_dev_encode_body / plz4hip_dev_duplex_body: the records land back to back -- the frame's block section, byte for byte
+    what blk.CompressToBlk + the writer's in-order emission produce (blk/blk.go:69-109) -- with recOff / recLen as
+    plz4hip_dev_compact_records makes them; also when the call runs in groups (the scan continues across them), with and without
+    block checksums, into a body that is too small (what fits is written, recOff says the rest), and at level 2."""
+    import torch
+    from plz4_amd._native import Engine
+    if budget_mib:
+        monkeypatch.setenv("PLZ4HIP_L1_BUDGET_MIB", str(budget_mib))
+    e = Engine(0)
+    bsz = 4 << 20
+    data = synth.make("M", 6 * bsz + 4321, bsz)
+    nb = (data.size + bsz - 1) // bsz
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(data).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for cs in (True, False):
+        if level == 1:
+            want = [orc.block_record(data[o:o + bsz], bsz, cs) for o in range(0, data.size, bsz)]
+        else:
+            want = []
+            for o in range(0, data.size, bsz):
+                blk = data[o:o + bsz]
+                r, c = ref.compress_hc(blk, bsz, 2)
+                payload, word = (blk, 0x80000000 | blk.size) if r == 0 else (c[:r], r)
+                rec = np.uint32(word).tobytes() + payload.tobytes() + (np.uint32(orc.xxh32(np.ascontiguousarray(payload))).tobytes() if cs else b"")
+                want.append(np.frombuffer(rec, np.uint8))
+        wantBody = np.concatenate(want)
+        d_body = torch.zeros(wantBody.size + 100, dtype=torch.uint8, device=dev)
+        d_off = torch.full((nb + 1,), -1, dtype=torch.int64, device=dev)
+        d_len = torch.zeros(nb, dtype=torch.int32, device=dev)
+        e.dev_encode_body(d_src.data_ptr(), data.size, bsz, cs, d_body.data_ptr(), d_body.numel(), d_off.data_ptr(), d_len.data_ptr(), s, level=level)
+        torch.cuda.synchronize()
+        off = d_off.cpu().numpy(); ln = d_len.cpu().numpy()
+        assert [int(x) for x in ln] == [w.size for w in want] and int(off[0]) == 0 and int(off[-1]) == wantBody.size
+        assert np.array_equal(np.diff(off), ln) and np.array_equal(d_body[:wantBody.size].cpu().numpy(), wantBody)
+        # too small a body: the records that fit are there, recOff tells the whole length
+        small = int(off[3]) + 10
+        d_body2 = torch.zeros(small, dtype=torch.uint8, device=dev)
+        e.dev_encode_body(d_src.data_ptr(), data.size, bsz, cs, d_body2.data_ptr(), small, d_off.data_ptr(), d_len.data_ptr(), s, level=level)
+        torch.cuda.synchronize()
+        assert int(d_off[-1].item()) == wantBody.size and np.array_equal(d_body2[:int(off[3])].cpu().numpy(), wantBody[:int(off[3])])
+    if level == 1:
+        # the duplex form: this batch's body beside the decode of another body
+        dataB = synth.make("T", 5 * bsz + 77, bsz)
+        recsB = [orc.block_record(dataB[o:o + bsz], bsz, True) for o in range(0, dataB.size, bsz)]
+        nB = len(recsB)
+        offB = np.zeros(nB + 1, dtype=np.int64); offB[1:] = np.cumsum([r.size for r in recsB])
+        d_bodyB = torch.from_numpy(np.concatenate(recsB)).to(dev); d_offB = torch.from_numpy(offB).to(dev)
+        d_out = torch.zeros(nB * bsz, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(nB, dtype=torch.int32, device=dev); d_st = torch.full((nB,), -9, dtype=torch.int32, device=dev)
+        want = [orc.block_record(data[o:o + bsz], bsz, True) for o in range(0, data.size, bsz)]
+        wantBody = np.concatenate(want)
+        d_body = torch.zeros(wantBody.size, dtype=torch.uint8, device=dev)
+        e.dev_duplex_body(d_src.data_ptr(), data.size, bsz, True, d_body.data_ptr(), d_body.numel(), d_off.data_ptr(), d_len.data_ptr(),
+                          d_bodyB.data_ptr(), d_offB.data_ptr(), nB, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert int(d_off[-1].item()) == wantBody.size and np.array_equal(d_body.cpu().numpy(), wantBody)
+        assert int(d_st.abs().sum().item()) == 0 and np.array_equal(d_out[:dataB.size].cpu().numpy(), dataB)
+    e.close()
+
+
 def test_gpu_level1_in_groups(orc, monkeypatch):
     """The staged level-1 call keeps 9 bytes of workspace per possible sequence of the blocks of one group; a call that does not
     fit the memory set aside runs in groups of equal size.  A 40 MiB budget makes 4 MiB blocks go four to a group: records and raw
