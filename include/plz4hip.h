@@ -29,7 +29,13 @@
  * per input byte of the blocks in flight (chain, per-hash lists, sequence records of the segments), level 12 22.5 (the search results as well), level 2 2.25, out
  * of a quarter of the device memory that is free when the call arrives, at most 64 GiB; a call whose blocks do not fit runs in
  * groups.  A caller that owns the GPU raises the budget with PLZ4HIP_HC_BUDGET_GIB (these kernels live on blocks in flight).
- * Other environment switches, for tests and experiments only: PLZ4HIP_HC_OVERLAP_OFF / _MIN / _GROUPS (levels 3..11: a call of 2048
+ * With a dictionary and / or linked blocks the HC levels run the same designs over segment + block (strides for 4 MiB + 64 KiB).
+ * A DECODE call of few blocks (decompress_batch, decode_records and their dev_ forms, up to PLZ4HIP_DX_MAX_BLOCKS = 128 blocks of up
+ * to 4 MiB + 8 of output; 0 turns it off) is cut across the whole chip and keeps 8 bytes per input byte + 4 per output byte of
+ * the call's blocks (about 50 MiB per 4 MiB block) until plz4hip_ctx_trim; results and error codes are LZ4_decompress_safe's
+ * either way (a block that path will not answer for is decoded by the one-wavefront decoder inside the call).
+ * Other environment switches, for tests and experiments only: PLZ4HIP_HC_EXT_OFF (the one-thread HC parsers for dictionary / linked
+ * calls, rounds 1-3), PLZ4HIP_HC12_LAZY (level 12 with its searches made on demand), PLZ4HIP_HC_OVERLAP_OFF / _MIN / _GROUPS (levels 3..11: a call of 2048
  * blocks or more runs in four or more groups, the list builder of the next group on a second stream of the ctx beside the walk
  * of the current one), PLZ4HIP_DUPLEX=P,D / PLZ4HIP_DUPLEX_PRIO (parser + decoder waves per workgroup of the duplex call),
  * PLZ4HIP_HC_SEGS / PLZ4HIP_HC_MIN_SEG (segments a block is walked

@@ -98,7 +98,7 @@ DEV int win20_fwd(const Win20& p, const Win20& c)
 // by unrolling (grid(S2,S0,S1), grid(S0,S1,S2), grid(S1,S2,S0)), not by copies.
 #if defined(PLZ4_EMU)
 #define SHFLF(x, f, l) ((x)[(l) & 63].f)
-unsigned long long plz4_emu_cnt[8];               // test diagnostics: [0] grid batches, [1] primes, [2] atomics out of order, [4] long matches measured, [5] batches whose commit
+unsigned long long plz4_emu_cnt[8];               // test diagnostics: [0] grid batches, [1] primes, [2] atomics out of order, [3] second rounds for a long match alone, [4] long matches measured, [5] batches whose commit
                                                   // returned another entry to a probe, [6] batches with a second round, [7] entries outside the registers
 #define EMU_CNT(i, v) (plz4_emu_cnt[(i)] += (unsigned long long)(v))
 #else
@@ -162,7 +162,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
         //           neither hit nor length of any probe changed, the walk stands (only offsets moved).  Else the commits are
         //           taken back (min with what each displaced restores the slots) and the round is repeated on the new
         //           candidates.  The sequential parse is the one consistent outcome (a lane depends on lower lanes only), so the
-        //           first round that verifies is it.  Three rounds without agreement, or an entry whose window is not in the
+        //           first round that verifies is it.  Four rounds without agreement, or an entry whose window is not in the
         //           registers: commits taken back, the generic batch takes over.
         // The loads are unconditional, so the number of memory operations in flight at any point of the loop is fixed.
         auto grid = [&](LVREF(GStage, prev), LVREF(GStage, cur), LVREF(GStage, next), const int base) -> int {
@@ -375,6 +375,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 if (trouble) {
                     // ---- rounds of walk -> commit -> verify (the walk with the long matches measured) until one verifies
                     EMU_CNT(6, 1); STAT(P_REPAIR, 1);
+                    EMU_CNT(3, (diff | misorder | noRegs) == 0);                       // (only because of a match longer than the window)
                     if (misorder | noRegs) { EMU_CNT(2, misorder != 0); EMU_CNT(7, noRegs != 0); giveUp = true; }
                     for (int round = 1; !giveUp; ++round) {
                         {                                                      // take the last round's commits back
