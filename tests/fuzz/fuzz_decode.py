@@ -63,6 +63,52 @@ def make_block(rng, nseq):
     return np.frombuffer(bytes(comp), dtype=np.uint8).copy(), np.frombuffer(bytes(plain), dtype=np.uint8).copy()
 
 
+def main_dx(iters=60, seed=11, gpu=False):
+    orc = Oracle()
+    rng = np.random.default_rng(seed)
+    blocks = [make_block(rng, int(rng.integers(1500, 9000))) for _ in range(iters)]
+    bad = taken = 0
+    if gpu:
+        from plz4_amd._native import Engine
+        eng = Engine(0)
+        for lo in range(0, len(blocks), 12):
+            part = blocks[lo:lo + 12]
+            for spare in (0, 100):
+                res, outs = eng.decompress_batch([c for c, _ in part], [p.size + spare for _, p in part])
+                for i, ((c, p), r, o) in enumerate(zip(part, res, outs)):
+                    if int(r) != p.size or not np.array_equal(o[:p.size], p):
+                        bad += 1; print("GPU MISMATCH (dx)", lo + i, c.size, p.size, int(r))
+            # damaged copies: the call's results are the oracle's, codes included
+            dam = []
+            for c, p in part:
+                d = c.copy(); i = int(rng.integers(0, d.size)); d[i] ^= 1 << int(rng.integers(0, 8)); dam.append((d, p.size + 8))
+            res, outs = eng.decompress_batch([d for d, _ in dam], [cap for _, cap in dam])
+            for i, ((d, cap), r, o) in enumerate(zip(dam, res, outs)):
+                a, da = orc.decompress_safe(d, cap)
+                if int(r) != a or (a >= 0 and not np.array_equal(o, da)):
+                    bad += 1; print("GPU MISMATCH (dx, damaged)", lo + i, d.size, int(r), a)
+        eng.close()
+    else:
+        from emulib import Emu
+        emu = Emu()
+        for i, (c, p) in enumerate(blocks):
+            for cap in (p.size, p.size + 100, max(p.size - 1, 0)):
+                a, da = orc.decompress_safe(c, cap)
+                r, dr, rounds = emu.dx_decode(c, cap)
+                if r == -999999:
+                    continue
+                taken += 1
+                if r != a or a < 0 or not np.array_equal(dr, da):
+                    bad += 1; print("MISMATCH (dx)", i, c.size, p.size, cap, a, r)
+            d = c.copy(); k = int(rng.integers(0, d.size)); d[k] ^= 1 << int(rng.integers(0, 8))
+            a, da = orc.decompress_safe(d, p.size + 8)
+            r, dr, rounds = emu.dx_decode(d, p.size + 8)
+            if r != -999999 and (r != a or a < 0 or not np.array_equal(dr, da)):
+                bad += 1; print("MISMATCH (dx, damaged)", i, d.size, a, r)
+    print("dx blocks", len(blocks), "answered", taken, "bad", bad)
+    return bad
+
+
 def main(iters=300, seed=11, gpu=False):
     orc = Oracle()
     rng = np.random.default_rng(seed)
@@ -104,5 +150,6 @@ def main(iters=300, seed=11, gpu=False):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if a != "--gpu"]
-    sys.exit(1 if main(*(int(x) for x in args), gpu="--gpu" in sys.argv) else 0)
+    args = [a for a in sys.argv[1:] if a not in ("--gpu", "--dx")]
+    fn = main_dx if "--dx" in sys.argv else main
+    sys.exit(1 if fn(*(int(x) for x in args), gpu="--gpu" in sys.argv) else 0)

@@ -3,7 +3,7 @@ liblz4 in oracle/_ref driven the way clz4.go drives it (StreamCtxHC, StreamLinke
 Not part of the test-suite (takes minutes); run from the repo root:  python tests/fuzz/fuzz_hc_dict.py [iters] [seed]
 PLZ4_FUZZ_LISTS=1: the blocks behind an external segment (linked blocks, blocks > 4 KiB under a dictionary) at levels 3..12 take
 the path the kernels run since round 4 -- chain and lists over segment + block, the walk in 1..16 segments, stitched, record emit
-(emu_compress_hc_lazy_ext) -- instead of the one-thread parsers of lz4hc_device.inl."""
+(emu_compress_hc_lazy_ext) -- instead of the one-thread parsers of lz4hc_device.inl.  `--gpu`: the kernels through the C ABI."""
 import os
 import sys
 
@@ -107,5 +107,54 @@ def main(iters=200, seed=11, levels=tuple(range(2, 13))):
     return bad
 
 
+def main_gpu(iters=40, seed=31, levels=tuple(range(2, 13))):
+    """The kernels through the C ABI: compress_batch_dict (StreamCtxHC: a dictionary, independent blocks, both sides of the 4 KiB
+    switch in one call) and encode_records_ex (StreamLinkedCtxHC: linked frames with and without a dictionary), every level."""
+    from plz4_amd._native import Engine
+    import hcdict
+    ref, orc, eng = Ref(), Oracle(), Engine(0)
+    rng = np.random.default_rng(seed)
+    bad = tot = 0
+    for it in range(iters):
+        kind = it % 5
+        dlen = int(rng.choice([0, 3, 5, 100, 4000, 40000, 65536, 70000]))
+        sizes = [int(rng.choice([0, 13, 200, 4096, 4097, 5000, 20000, 66000, 150000])) for _ in range(5)]
+        whole = gen(rng, dlen + sum(sizes), kind, it)
+        if kind == 1 and whole.size > 40:
+            whole[max(dlen - 20, 0):dlen + 20] = whole[max(dlen - 20, 0)]
+        dct = whole[:dlen].copy()
+        blocks, o = [], dlen
+        for sz in sizes:
+            blocks.append(np.ascontiguousarray(whole[o:o + sz])); o += sz
+        dtrunc = np.ascontiguousarray(dct[-65536:] if dct.size > 65536 else dct)
+        d = eng.dict_create(np.ascontiguousarray(dct))
+        for lvl in levels:
+            keep, daddr = ref.new_dict_ctx_hc(dtrunc, lvl)
+            comp = ref.stream_ctx_hc(lvl, daddr)
+            for rule in (lambda n: orc.bound(n), lambda n: max(n, 1), lambda n: max(n // 2, 1)):
+                caps = [rule(b.size) for b in blocks]
+                res, outs = eng.compress_batch_dict(blocks, caps, d, level=lvl)
+                for k, (b, cap, r, out) in enumerate(zip(blocks, caps, res, outs)):
+                    a, da = comp(b, cap); tot += 1
+                    if int(r) != a or not np.array_equal(out, da):
+                        bad += 1; print("GPU INDIE MISMATCH it", it, "kind", kind, "lvl", lvl, "dlen", dlen, "n", b.size, "cap", cap, a, int(r))
+            bsz = max(max(sizes), 1)
+            for use_dict in (True, False):
+                want, _ = hcdict.ref_records(ref, orc, blocks, bsz, lvl, True, dct if use_dict else None)
+                got = eng.encode_records_ex(blocks, bsz, True, linked=True, d=d if use_dict else None, level=lvl)
+                for k, (g_, w) in enumerate(zip(got, want)):
+                    tot += 1
+                    if g_.tobytes() != w:
+                        bad += 1; print("GPU LINKED MISMATCH it", it, "kind", kind, "lvl", lvl, "dict", use_dict, "k", k, "n", blocks[k].size)
+        eng.dict_destroy(d)
+        if it % 5 == 4:
+            print("iter", it + 1, "total", tot, "bad", bad, flush=True)
+    eng.close()
+    print("total", tot, "bad", bad)
+    return bad
+
+
 if __name__ == "__main__":
+    if "--gpu" in sys.argv:
+        sys.exit(1 if main_gpu(*(int(x) for x in sys.argv[1:] if x != "--gpu")) else 0)
     sys.exit(1 if main(*(int(x) for x in sys.argv[1:])) else 0)

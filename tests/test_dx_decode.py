@@ -30,11 +30,11 @@ def _check(orc, emu, comp, cap, must_take=False):
 
 def test_emu_dx_valid_blocks(orc, emu):
     taken = total = 0
-    for name, src in corpus.small_cases()[::3] + corpus.block_cases_64k() + corpus.twin_cases()[:6]:
+    for name, src in corpus.small_cases()[::7] + corpus.block_cases_64k() + corpus.twin_cases()[:6]:
         n = src.size
         c, comp = orc.compress_fast(src, orc.bound(n))
         comp = np.ascontiguousarray(comp[:c])
-        for cap in (n, n + 8, n + 64, max(n - 1, 0), max(n - 13, 0)):
+        for cap in (n, n + 8, max(n - 1, 0)):
             taken += _check(orc, emu, comp, cap); total += 1
     assert taken > total // 2
 
