@@ -215,17 +215,30 @@ def crossover(args):
             "cpu": "reference liblz4 1.10.0 (oracle/_ref) + oracle xxh32, one block per task" if ref is not None else None}
 
 
-def memory_plan(B: int, world: int, gather_rank0: bool, duplex: bool, ratio: float, level: int = 1):
+def same_bytes(a, b, chunk: int = 1 << 30) -> bool:
+    """torch.equal in pieces: the comparison of two 24 GiB buffers would otherwise allocate a third one for its mask"""
+    import torch
+    n = a.numel()
+    if n != b.numel():
+        return False
+    for lo in range(0, n, chunk):
+        if not torch.equal(a[lo:lo + chunk], b[lo:lo + chunk]):
+            return False
+    return True
+
+
+def memory_plan(B: int, world: int, gather_rank0: bool, duplex: bool, ratio: float, level: int = 1, pipelines: int = 1):
     """GiB this bench holds on the busiest rank (rank 0) for B blocks per GPU: its own buffers, the library's level-1 workspace
     (9 bytes per possible sequence -- a sequence takes at least 4 input bytes -- plus the chunk tables: launch_l1 in plz4hip.hip) and,
     when the framed output is gathered, the assembled frame body and the receive pieces (plz4_amd/shard.py)."""
     S = B * BSZ
     C = ratio * S
     g = 2.0**30
+    P = max(1, pipelines)                     # (every pipeline: its own plaintext out, two frame bodies, one record workspace)
     plan = {
-        "src": S / g, "out": S / g, "stage": (B * (BSZ + 16) / g) if level > 2 else 0.0,
-        "frame_body": min(B * (BSZ + 8), C * 1.02 + (1 << 20)) / g * (2 if duplex else 1),
-        "l1_workspace": (B * ((BSZ // 4 + 3 + 63) // 64 * 64) * 9 + B * 1024 * 8) / g if level <= 2 else 0.0,
+        "src": S / g, "out": P * S / g, "stage": (B * (BSZ + 16) / g) if level > 2 else 0.0,
+        "frame_body": P * min(B * (BSZ + 8), C * 1.02 + (1 << 20)) / g * (2 if duplex else 1),
+        "l1_workspace": P * (B * ((BSZ // 4 + 3 + 63) // 64 * 64) * 9 + B * 1024 * 8) / g if level <= 2 else 0.0,
     }
     if gather_rank0 and world > 1:
         plan["gathered_frame"] = world * C / g
@@ -256,6 +269,11 @@ def main():
                     help="level 1 only.  1 (default): a step is ONE duplex call (plz4hip_dev_duplex_records): the level-1 encode of this step's batch beside the "
                          "decode of the frame body the previous step produced (the decoder's waves share every CU with the parser's), "
                          "then scan + compact; 0: encode -> frame body -> decode of the same batch, one after the other")
+    ap.add_argument("--pipelines", type=int, default=int(os.environ.get("PLZ4_BENCH_PIPELINES", "0")),
+                    help="level-1 duplex steps on one GPU: the steps alternate over this many HIP streams, each with its own frame bodies, "
+                         "plaintext buffer and (inside the library) record workspace; a step's call decodes the body the same stream's "
+                         "previous call wrote.  The emit kernels of one step then run beside the parse of the next.  0 (default): 2 on "
+                         "one GPU, 1 with N > 1 (rank 0 has the assembled frame to hold)")
     ap.add_argument("--gather", choices=("rank0", "none"), default=os.environ.get("PLZ4_BENCH_GATHER", "rank0"),
                     help="N > 1: rank0 (default) = the framed output is gathered to rank 0 over RCCL and interleaved into ONE frame body "
                          "there (a single io.Writer); none = every rank keeps its frame body, block i on rank i mod N (SURVEY 8d config 3: "
@@ -306,10 +324,13 @@ def main():
     B = args.blocks
     S = B * BSZ
     t0 = time.time()
+    NPIPE = args.pipelines if args.pipelines > 0 else (1 if multi else 2)
+    if not (bool(args.duplex) and args.level == 1 and not args.decode_only and args.pipe <= 1):
+        NPIPE = 1
     if rank == 0:
         free0, total0 = torch.cuda.mem_get_info(dev)
         dup0 = bool(args.duplex) and args.level == 1 and not args.decode_only
-        plan = memory_plan(B, world, gather_rank0, dup0, 0.40, args.level)
+        plan = memory_plan(B, world, gather_rank0, dup0, 0.40, args.level, NPIPE)
         log("rank 0 memory plan, GiB (%d rank(s), gather %s): %s; device %.1f GiB, free %.1f GiB" %
             (world, args.gather if multi else "-", plan, total0 / 2**30, free0 / 2**30))
         if world == 1 and multi:                                               # the dry run also says what rank 0 of a full node would hold
@@ -360,6 +381,11 @@ def main():
         pt["offs"] = [pt["off"], torch.zeros_like(pt["off"])]
         pt["cur"] = 0
         pt["gat_ev"] = [None, None]                                          # N > 1: the exchange that last read each body
+        pt["stream"] = None                                                  # (the current stream, below)
+    else:
+        NPIPE = 1
+    pipes = [parts[0]] if duplex else []                                     # the further pipelines once the gate has sized a body
+    calls = {"n": 0}
     s_enc = torch.cuda.current_stream()
     s_dec = torch.cuda.Stream(device=dev) if NP > 1 else s_enc
     # N > 1: the framed-output gather (RCCL send/recv + the interleave on rank 0) runs on its own stream, next to the decode
@@ -392,24 +418,26 @@ def main():
             if e: e[5].record(s_enc)
 
     def step_duplex(ev=None):
-        """one duplex call: encode of this step's batch straight into a frame body + decode of the previous step's frame body"""
+        """one duplex call: encode of this step's batch straight into a frame body + decode of the frame body the same pipeline's
+        previous call wrote (one pipeline: the previous step's).  Calls alternate over the pipelines, each on its own stream."""
         gather["live"] = []
-        pt = parts[0]
+        pt = pipes[calls["n"] % len(pipes)]; calls["n"] += 1
+        st = pt["stream"] if pt["stream"] is not None else s_enc
         e = ev[0] if ev else None
         prv = pt["cur"]; cur = 1 - prv
-        if e: e[0].record(s_enc)
+        if e: e[0].record(st)
         # (two bodies alternate: the one this call writes is the one the exchange of the step BEFORE LAST read -- that exchange has
         # to be over; the last step's, which reads the body this call decodes, runs on under this call)
         if s_gat is not None and pt["gat_ev"][cur] is not None:
-            s_enc.wait_event(pt["gat_ev"][cur])
+            st.wait_event(pt["gat_ev"][cur])
         eng.dev_duplex_body(pt["src"].data_ptr(), pt["bytes"], BSZ, True, pt["bodies"][cur].data_ptr(), pt["bodies"][cur].numel(),
                             pt["offs"][cur].data_ptr(), pt["len"].data_ptr(),
                             pt["bodies"][prv].data_ptr(), pt["offs"][prv].data_ptr(), pt["nb"], BSZ, True,
-                            pt["out"].data_ptr(), BSZ, BSZ, pt["res"].data_ptr(), pt["st"].data_ptr(), s_enc.cuda_stream)
-        if e: e[1].record(s_enc)
+                            pt["out"].data_ptr(), BSZ, BSZ, pt["res"].data_ptr(), pt["st"].data_ptr(), st.cuda_stream)
+        if e: e[1].record(st)
         pt["cur"] = cur; pt["body"] = pt["bodies"][cur]; pt["off"] = pt["offs"][cur]
         packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
-        packed.record(s_enc)
+        packed.record(st)
         if gather_rank0:
             s_gat.wait_event(packed)
             with torch.cuda.stream(s_gat):
@@ -417,8 +445,8 @@ def main():
                 if e: e[3].record(s_gat)
                 pt["gat_ev"][cur] = torch.cuda.Event(); pt["gat_ev"][cur].record(s_gat)
         elif e:
-            e[3].record(s_enc)
-        if e: e[4].record(s_enc); e[5].record(s_enc)
+            e[3].record(st)
+        if e: e[4].record(st); e[5].record(st)
 
     def step(ev=None, serial=False):
         """ev: per part [enc0, enc1, cmp1, gat1, dec0, dec1] events."""
@@ -480,7 +508,7 @@ def main():
             break
     assert sum(int(pt["st"].abs().sum().item()) for pt in parts) == 0, "decode status != OK"
     assert sum(int(pt["res"].to(torch.int64).sum().item()) for pt in parts) == S, "decoded size mismatch"
-    assert torch.equal(d_out, d_src), "round trip mismatch"
+    assert same_bytes(d_out, d_src), "round trip mismatch"
     C_bytes = sum(int(pt["off"][-1].item()) for pt in parts)
     d_off, d_body = parts[0]["off"], parts[0]["body"]
     check_pairs = []
@@ -504,9 +532,31 @@ def main():
         d_out.zero_()                                                        # what the timed steps decode is checked again below
         # the same input every step, so the same body: the second one is that size + 2 % (compact skips what would not fit and
         # the check after the timed region would notice), which leaves rank 0 of an 8-GPU run room for the assembled frame
-        parts[0]["bodies"][1] = torch.empty(min(parts[0]["body"].numel(), int(C_bytes * 1.02) + (1 << 20)), dtype=torch.uint8, device=dev)
+        bcap = min(parts[0]["body"].numel(), int(C_bytes * 1.02) + (1 << 20))
+        parts[0]["bodies"][1] = torch.empty(bcap, dtype=torch.uint8, device=dev)
+        if NPIPE > 1:
+            parts[0]["stream"] = torch.cuda.Stream(device=dev)               # (a stream of its own like the others', not the default one)
+        for i in range(1, NPIPE):
+            # a further pipeline: its own stream, plaintext buffer, two bodies and offsets; primed with one encode of the batch, so
+            # that its first duplex call has a body to decode (the library gives the second stream a record workspace of its own)
+            q = {"b0": 0, "nb": B, "bytes": S, "src": d_src, "out": torch.zeros(S, dtype=torch.uint8, device=dev),
+                 "bodies": [torch.empty(bcap, dtype=torch.uint8, device=dev) for _ in range(2)],
+                 "offs": [torch.zeros(B + 1, dtype=torch.int64, device=dev) for _ in range(2)],
+                 "len": torch.zeros(B, dtype=torch.int32, device=dev), "res": torch.zeros(B, dtype=torch.int32, device=dev),
+                 "st": torch.zeros(B, dtype=torch.int32, device=dev), "cur": 0, "gat_ev": [None, None],
+                 "stream": torch.cuda.Stream(device=dev)}
+            q["body"] = q["bodies"][0]; q["off"] = q["offs"][0]
+            eng.dev_encode_body(q["src"].data_ptr(), q["bytes"], BSZ, True, q["body"].data_ptr(), q["body"].numel(),
+                                q["off"].data_ptr(), q["len"].data_ptr(), q["stream"].cuda_stream, level=1)
+            pipes.append(q)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step_decode() if args.decode_only else (step_duplex() if duplex else step())
+    if duplex and len(pipes) > 1:
+        # (untimed, whatever --warmup says: every further pipeline makes one call, which also puts its record workspace in place)
+        torch.cuda.synchronize()
+        while calls["n"] % len(pipes) != 0 or calls["n"] < len(pipes):
+            step_duplex()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -520,17 +570,23 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    free_t, total_t = torch.cuda.mem_get_info(dev)
+    held_timed = round((total_t - free_t) / 2**30, 1)
     if duplex:
-        # every timed step decoded the body of the step before it (the first one the warm-up's or the gate's): the plaintext must
-        # be back, and so must the plaintext of the last body, decoded here outside the timed region
-        pt = parts[0]
-        if args.steps + args.warmup > 0:
-            assert int(pt["st"].abs().sum().item()) == 0 and torch.equal(d_out, d_src), "duplex: round trip mismatch"
-        d_out.zero_()
-        eng.dev_decode_records(pt["body"].data_ptr(), pt["off"].data_ptr(), pt["nb"], BSZ, True, pt["out"].data_ptr(), BSZ, BSZ,
-                               pt["res"].data_ptr(), pt["st"].data_ptr(), s_enc.cuda_stream)
-        torch.cuda.synchronize()
-        assert int(pt["st"].abs().sum().item()) == 0 and torch.equal(d_out, d_src), "duplex: last body does not decode to the input"
+        # every timed step decoded the body its pipeline's previous call wrote (the first ones the warm-up's or the gate's): the
+        # plaintext must be back, and so must the plaintext of each pipeline's last body, decoded here outside the timed region
+        for pt in pipes:
+            assert int(pt["st"].abs().sum().item()) == 0 and same_bytes(pt["out"], d_src), "duplex: round trip mismatch"
+            pt["out"].zero_()
+            eng.dev_decode_records(pt["body"].data_ptr(), pt["off"].data_ptr(), pt["nb"], BSZ, True, pt["out"].data_ptr(), BSZ, BSZ,
+                                   pt["res"].data_ptr(), pt["st"].data_ptr(), s_enc.cuda_stream)
+            torch.cuda.synchronize()
+            assert int(pt["st"].abs().sum().item()) == 0 and same_bytes(pt["out"], d_src), "duplex: last body does not decode to the input"
+        if len(pipes) > 1:
+            # the further pipelines' buffers are not needed for the serial leg below (nor is the library's second workspace)
+            del pipes[1:]
+            pt = q = None
+            torch.cuda.synchronize(); torch.cuda.empty_cache()
     serial_leg = None
     if duplex and not multi:
         # beside the headline: the same K steps as encode -> frame body -> decode of the same batch, one call after the other (the
@@ -619,15 +675,26 @@ def main():
             # one call does both directions: its algorithmic bytes are the encode's (S read + C written) plus the decode's (C read + S
             # written), over the call's time (k_l1_duplex + the four emit kernels)
             enc_kernel = "k_l1_duplex+k_l1_sizes+k_l1_scan+k_l1_write+k_l1_finish"
-            ach = 2 * (S + C_bytes) / (enc_ms * 1e-3) / 1e9
+            # (several pipelines: the calls of different streams overlap, so a call's own begin-to-end time on its stream covers
+            # the other stream's kernels too -- the rate is then taken over the timed region: K calls' bytes over the K steps' time)
+            ach = 2 * (S + C_bytes) / ((ms_step if NPIPE > 1 else enc_ms) * 1e-3) / 1e9
             out["config"]["workload"] = out["config"]["workload"].replace(
                 "step = encode->frame body->decode",
                 "step = ONE duplex call (encode of this step's batch beside the decode of the frame body the previous step produced; every "
                 "step is one full encode and one full decode, the last body is decoded and checked after the timed region) -> frame body")
             out["config"]["duplex"] = True
+            out["config"]["pipelines"] = NPIPE
+            if NPIPE > 1:
+                out["config"]["workload"] = out["config"]["workload"].replace(
+                    "the frame body the previous step produced", "the frame body the same stream's previous call produced (the steps alternate "
+                    "over %d HIP streams, each with its own bodies, plaintext buffer and record workspace, so the emit kernels of one "
+                    "step run beside the parse of the next)" % NPIPE)
             out["roofline"] = {"bound": "hbm", "kernel": enc_kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None}
             out["ms"] = {"duplex_call": round(enc_ms, 3), "scan_compact": round(cmp_ms, 3), "frame_gather": round(gat_ms, 3)}
+            if NPIPE > 1:
+                out["ms"]["duplex_call_note"] = "begin to end on the call's own stream, %d calls in flight: not a kernel time (serial_step has those)" % NPIPE
+                out["roofline"]["over"] = "the timed region (overlapping launches): 2 (S + C) x steps / elapsed"
             del out["roofline_decode"], out["enc_MiBps_per_gpu"], out["dec_MiBps_per_gpu"]
             if serial_leg:
                 el2, (e2, c2, g2, d2) = serial_leg
@@ -653,7 +720,7 @@ def main():
                 out[key]["traffic"] = t["bytes"]; out[key]["traffic_source"] = t["source"]; out[key]["traffic_per"] = t["per"]
         free1, total1 = torch.cuda.mem_get_info(dev)
         out["config"]["gather"] = (args.gather if multi else None)
-        out["memory_gib"] = {"plan": plan, "held_at_end": round((total1 - free1) / 2**30, 1), "device": round(total1 / 2**30, 1)}
+        out["memory_gib"] = {"plan": plan, "held_in_timed_region": held_timed, "held_at_end": round((total1 - free1) / 2**30, 1), "device": round(total1 / 2**30, 1)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pool, level=args.level, check=check_pairs)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -1388,29 +1388,34 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
     const uint64_t far = mL & ~coopM & BALLOT((int64_t)sp[I_] + ml[I_] <= op0);
     if (kLds) {
         const int total = RL(acc, last);                       // bytes this batch produces
-        // `rem` (4..18) bytes of (a, b) to d, for the lanes that are `on` -- without a branch: five stores per lane, each to its
-        // place or, when it has nothing to write, to the dump bytes behind the buffer (a divergent `if` costs this machine
-        // ~45 cycles whether any lane takes it or not, a redirected store costs a select)
-        auto put_match = [&](uint8_t* d, const v16u_t& a, uint32_t b, int rem, bool on) {
-            uint8_t* const dump = lb + kDecDump;
-            const uint64_t lo = (uint64_t)a.w[0] | ((uint64_t)a.w[1] << 32), hi = (uint64_t)a.w[2] | ((uint64_t)a.w[3] << 32);
-            const bool c16 = on & (rem >= 16), c8 = on & ((rem & 8) != 0);
-            st64u((c16 | c8) ? d : dump, lo);
-            st64u(c16 ? d + 8 : dump, hi);
-            uint64_t cur = c16 ? (uint64_t)b : (c8 ? hi : lo);
-            uint8_t* e = d + (c16 ? 16 : 0) + (c8 ? 8 : 0);
-            const bool c4 = on & ((rem & 4) != 0), c2 = on & ((rem & 2) != 0), c1 = on & ((rem & 1) != 0);
-            st32u(c4 ? e : dump, (uint32_t)cur);
-            e += c4 ? 4 : 0; cur = c4 ? (cur >> 32) : cur;
-            st16u(c2 ? e : dump, (uint16_t)cur);
-            e += c2 ? 2 : 0; cur = c2 ? (cur >> 16) : cur;
-            *(c1 ? e : dump) = (uint8_t)cur;
+        // A match of 4..18 bytes travels as four overlapping pieces: [0,4) and [len-4,len) always, [len-8,len-4) from 8 bytes on,
+        // [4,12) from 12 on -- together they cover every length, and where two overlap they carry the same bytes.  Every piece
+        // has a fixed place per lane and batch, so a round is four loads and four stores; a lane that is not part of the round
+        // (or a piece its length does not have) stores to the dump bytes behind the buffer: a divergent `if` costs this machine
+        // ~45 cycles whether any lane takes it or not, a redirected store costs a select.
+        LV(int, mdst); LV(int, qoff);
+        LANES({
+            mdst[I_] = kDecTail + (outStart[I_] - (int)op0) + (ll[I_] & 0xFFFF);       // where the match goes, as an offset into lb
+            qoff[I_] = mdst[I_] - off[I_];                                             // ... and where it comes from
+        })
+        LV(uint32_t, g0); LV(uint32_t, g1); LV(uint32_t, g2); LV(uint64_t, g3);
+        auto put_pieces = [&](const uint64_t who) {
+            LANES({
+                const bool on = (who >> LANE) & 1;
+                const int len = on ? ml[I_] : 0, at = on ? mdst[I_] : (int)kDecDump;
+                st32u(lb + at, g0[I_]);
+                st32u(lb + at + max_(len - 4, 0), g1[I_]);
+                st32u(lb + (len >= 8 ? at + len - 8 : (int)kDecDump), g2[I_]);
+                st64u(lb + (len >= 12 ? at + 4 : (int)kDecDump + 8), g3[I_]);
+            })
         };
         // far matches: their bytes are requested from memory first ...
-        LV(v16u_t, fa); LV(uint32_t, fb);
         LANES({
-            fb[I_] = 0; fa[I_].w[0] = 0; fa[I_].w[1] = 0; fa[I_].w[2] = 0; fa[I_].w[3] = 0;
-            if ((far >> LANE) & 1) { fa[I_] = *(const v16u_t*)(dst + sp[I_]); fb[I_] = ld16u(dst + sp[I_] + 16); }
+            g0[I_] = 0; g1[I_] = 0; g2[I_] = 0; g3[I_] = 0;
+            if ((far >> LANE) & 1) {
+                const uint8_t* q = dst + sp[I_]; const int len = ml[I_];
+                g0[I_] = ld32u(q); g1[I_] = ld32u(q + len - 4); g2[I_] = ld32u(q + max_(len - 8, 0)); g3[I_] = ld64u(q + 4);
+            }
         })
         // ... the tail of what is already written, if LDS does not hold it (after a sequential step)
         if (*tailAt != op0) {
@@ -1426,32 +1431,30 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         })
         const unsigned long long td3 = STAT_NOW(); (void)td3;
         STAT(2, td3 - td2);
-        LANES({ put_match(lb + kDecTail + (outStart[I_] - (int)op0) + (ll[I_] & 0xFFFF), fa[I_], fb[I_], ml[I_], (far >> LANE) & 1); })
+        put_pieces(far);
         const unsigned long long td4 = STAT_NOW(); (void)td4;
         STAT(3, td4 - td3);
         // the rest in dependency order, LDS to LDS (see the memory version below for the rule)
         for (uint64_t pend = mL & ~far; pend; ) {
             const int f  = ctz64(pend);
-            const int lo = RL(outStart, f) + (RL(ll, f) & 0xFFFF) - (int)op0;           // relative to op0
+            const int lo = RL(mdst, f);                                                 // (an offset into lb)
             LDS_FENCE();
             if ((coopM >> f) & 1) {
-                const int len = RL(ml, f); const int64_t s0 = RL(sp, f);
-                if (s0 + len <= op0) { LANES({ for (int i = LANE; i < len; i += 64) lb[kDecTail + lo + i] = dst[s0 + i]; }) }   // older than the window: from memory
-                else wave_copy_match(lb, kDecTail + lo, RL(off, f), len);
+                const int len = RL(ml, f); const int64_t s0 = op0 + (RL(qoff, f) - kDecTail);
+                if (s0 + len <= op0) { LANES({ for (int i = LANE; i < len; i += 64) lb[lo + i] = dst[s0 + i]; }) }   // older than the window: from memory
+                else wave_copy_match(lb, lo, RL(off, f), len);
                 pend &= pend - 1;
             } else {
                 STAT(8, 1);
-                const uint64_t go = pend & ~coopM & BALLOT(sp[I_] + ml[I_] - (int)op0 <= lo);
+                const uint64_t go = pend & ~coopM & BALLOT(qoff[I_] + ml[I_] <= lo);
                 LANES({
                     if ((go >> LANE) & 1) {
-                        const uint8_t* q = lb + kDecTail + (sp[I_] - (int)op0);
-                        v16u_t a; const uint64_t q0 = ld64u(q), q1 = ld64u(q + 8);
-                        a.w[0] = (uint32_t)q0; a.w[1] = (uint32_t)(q0 >> 32); a.w[2] = (uint32_t)q1; a.w[3] = (uint32_t)(q1 >> 32);
-                        fa[I_] = a; fb[I_] = ld16u(q + 16);
+                        const uint8_t* q = lb + qoff[I_]; const int len = ml[I_];
+                        g0[I_] = ld32u(q); g1[I_] = ld32u(q + len - 4); g2[I_] = ld32u(q + max_(len - 8, 0)); g3[I_] = ld64u(q + 4);
                     }
                 })
                 LDS_FENCE();
-                LANES({ put_match(lb + kDecTail + (outStart[I_] - (int)op0) + (ll[I_] & 0xFFFF), fa[I_], fb[I_], ml[I_], (go >> LANE) & 1); })
+                put_pieces(go);
                 pend &= ~go;
             }
         }

@@ -1270,10 +1270,13 @@ struct plz4hip_ctx {
     // job on another stream waits for that event on the device (no host block).
     hipEvent_t   hcDone = nullptr; hipStream_t hcStream = nullptr; bool hcPending = false;
     hipStream_t  hashStream = nullptr;   // the streaming content checksum runs here, beside the codec kernels
-    // the level-1 workspace of the device-resident calls (the host-buffer calls have one per staging slot): one job at a time,
-    // ordered across streams on the device like the HC workspaces
-    L1Ws         l1;
-    hipEvent_t   l1Done = nullptr; hipStream_t l1Stream = nullptr; bool l1Pending = false;
+    // the level-1 workspaces of the device-resident calls (the host-buffer calls have one per staging slot): one job at a time
+    // each, ordered across streams on the device like the HC workspaces.  Two of them, so that calls on two streams need not
+    // wait for each other: the emit kernels of one call then run beside the parse of the next (the second one is only
+    // allocated when a second stream shows up while the first workspace is another stream's; PLZ4HIP_L1_WORKSPACES=1: one)
+    static constexpr int kL1Shared = 2;
+    L1Ws         l1[kL1Shared];
+    hipEvent_t   l1Done[kL1Shared] = {nullptr, nullptr}; hipStream_t l1Stream[kL1Shared] = {nullptr, nullptr}; bool l1Pending[kL1Shared] = {false, false};
     // levels 3..11 on independent blocks: the list builder of the next group of blocks runs on this stream beside the walk of the
     // current one (launch_hc)
     hipStream_t  hcBuildStream = nullptr; hipEvent_t evHcFork = nullptr, evHcHist = nullptr, evHcChain[2] = {nullptr, nullptr}, evHcFree[2] = {nullptr, nullptr};
@@ -1858,7 +1861,21 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     const bool mid = midDeclined != nullptr;
     a.rawMode = rawMode; a.blk0 = 0; a.nBlocks = nb;
     const bool shared = (ws == nullptr);
-    if (shared) ws = &c->l1;
+    int wsi = 0;
+    if (shared) {
+        // the workspace this stream used last; else one nobody has used yet; else the first one (and the wait below)
+        int nws = plz4hip_ctx::kL1Shared;
+        if (const char* v = getenv("PLZ4HIP_L1_WORKSPACES")) { if (atoi(v) == 1) nws = 1; }
+        int mine = -1, idle = -1, fresh = -1;
+        for (int i = 0; i < nws; ++i) {
+            if (c->l1[i].d && c->l1Stream[i] == s && mine < 0) mine = i;
+            if (c->l1[i].d && idle < 0 && (!c->l1Pending[i] || hipEventQuery(c->l1Done[i]) == hipSuccess)) idle = i;   // (its last job is over)
+            if (!c->l1[i].d && fresh < 0) fresh = i;
+        }
+        (void)hipGetLastError();                                                          // (hipErrorNotReady of the query)
+        wsi = mine >= 0 ? mine : (idle >= 0 ? idle : (fresh >= 0 ? fresh : 0));
+        ws = &c->l1[wsi];
+    }
     bool fused = maxLen <= 0 || maxLen > kSeqMaxBlock || getenv("PLZ4HIP_L1_FUSED") != nullptr;
     const size_t seqStride = round_up((size_t)(maxLen > 0 ? maxLen : 0) / 4 + 3, 64);     // + the dump entry (lz4_seq_device.inl)
     const int    maxChunks = (int)((seqStride + kSeqChunk - 1) / kSeqChunk);
@@ -1878,7 +1895,7 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
             const int nGroups = (int)((nb + grp - 1) / grp);
             per = (nb + nGroups - 1) / nGroups;
             if (need_for(per) <= ws->bytes) break;
-            if (shared && c->l1Pending) HIPCHK(c, hipEventSynchronize(c->l1Done));     // nothing may still use the old workspace
+            if (shared && c->l1Pending[wsi]) HIPCHK(c, hipEventSynchronize(c->l1Done[wsi]));     // nothing may still use the old workspace
             else if (!shared) HIPCHK(c, hipStreamSynchronize(s));
             if (ws->d) hipFree(ws->d);
             ws->d = nullptr; ws->bytes = 0;
@@ -1900,7 +1917,7 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         HIPCHK(c, hipGetLastError());
         return PLZ4HIP_OK;
     }
-    if (shared && c->l1Pending && c->l1Stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->l1Done, 0));
+    if (shared && c->l1Pending[wsi] && c->l1Stream[wsi] != s) HIPCHK(c, hipStreamWaitEvent(s, c->l1Done[wsi], 0));
     a.l1MaxLen = maxLen; a.l1SeqStride = (int64_t)seqStride; a.l1MaxChunks = maxChunks;
     a.l1Info = (SeqInfo*)ws->d;
     a.l1ChunkBytes = (uint32_t*)(ws->d + round_up((size_t)per * sizeof(SeqInfo), 256));
@@ -1959,9 +1976,9 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         HIPCHK(c, hipGetLastError());
     }
     if (shared) {
-        if (!c->l1Done) HIPCHK(c, hipEventCreateWithFlags(&c->l1Done, hipEventDisableTiming));
-        HIPCHK(c, hipEventRecord(c->l1Done, s));
-        c->l1Pending = true; c->l1Stream = s;
+        if (!c->l1Done[wsi]) HIPCHK(c, hipEventCreateWithFlags(&c->l1Done[wsi], hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->l1Done[wsi], s));
+        c->l1Pending[wsi] = true; c->l1Stream[wsi] = s;
     }
     return PLZ4HIP_OK;
 }
@@ -2120,12 +2137,14 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     }
     if (c->d_hc) hipFree(c->d_hc);
     if (c->d_h12) hipFree(c->d_h12);
-    if (c->l1Pending) hipEventSynchronize(c->l1Done);
-    if (c->l1.d) hipFree(c->l1.d);
+    for (int i = 0; i < plz4hip_ctx::kL1Shared; ++i) {
+        if (c->l1Pending[i]) hipEventSynchronize(c->l1Done[i]);
+        if (c->l1[i].d) hipFree(c->l1[i].d);
+        if (c->l1Done[i]) hipEventDestroy(c->l1Done[i]);
+    }
     if (c->d_lenCopy) hipFree(c->d_lenCopy);
     if (c->d_hcPfx) hipFree(c->d_hcPfx);
     if (c->lenDone) hipEventDestroy(c->lenDone);
-    if (c->l1Done) hipEventDestroy(c->l1Done);
     if (c->hcDone) hipEventDestroy(c->hcDone);
     if (c->hashStream) { hipStreamSynchronize(c->hashStream); hipStreamDestroy(c->hashStream); }
     if (c->hcBuildStream) { hipStreamSynchronize(c->hcBuildStream); hipStreamDestroy(c->hcBuildStream); }
@@ -2146,8 +2165,11 @@ int plz4hip_ctx_trim(plz4hip_ctx* c)
         if (sl.d) { hipFree(sl.d); sl.d = nullptr; sl.dcap = 0; }
         if (sl.l1.d) { hipFree(sl.l1.d); sl.l1.d = nullptr; sl.l1.bytes = 0; }
     }
-    if (c->l1Pending) { HIPCHK(c, hipEventSynchronize(c->l1Done)); c->l1Pending = false; }
-    if (c->l1.d) { hipFree(c->l1.d); c->l1.d = nullptr; c->l1.bytes = 0; }
+    for (int i = 0; i < plz4hip_ctx::kL1Shared; ++i) {
+        if (c->l1Pending[i]) { HIPCHK(c, hipEventSynchronize(c->l1Done[i])); c->l1Pending[i] = false; }
+        if (c->l1[i].d) { hipFree(c->l1[i].d); c->l1[i].d = nullptr; c->l1[i].bytes = 0; }
+        c->l1Stream[i] = nullptr;
+    }
     if (c->d_hc) { hipFree(c->d_hc); c->d_hc = nullptr; c->hcWaves = 0; }
     if (c->d_h12) { hipFree(c->d_h12); c->d_h12 = nullptr; c->h12Bytes = 0; }
     if (c->dxPending) { HIPCHK(c, hipEventSynchronize(c->dxDone)); c->dxPending = false; }

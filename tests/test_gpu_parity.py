@@ -615,3 +615,11 @@ def test_gpu_bench_modes_run_on_one_gpu():
         assert out.returncode == 0, out.stderr[-2000:]
         line = json.loads(out.stdout.strip().splitlines()[-1])
         assert line["value"] > 0 and ("k_l1_duplex" in line["roofline"]["kernel"]) == (dup == "1")
+    # one GPU, no gather: the duplex steps alternate over two streams by default (two record workspaces inside the library), three
+    # when asked, one when asked; an odd number of steps leaves the pipelines with different numbers of calls
+    for pipes, want in (((), 2), (("--pipelines", "3"), 3), (("--pipelines", "1"), 1)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--blocks", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                              *pipes], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["value"] > 0 and line["config"]["pipelines"] == want and line["serial_step"]["value"] > 0
