@@ -1358,18 +1358,18 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
 
     // exclusive prefix sum of the members' output lengths -> where each sequence writes
     LV(int, acc); LV(int, outStart); LV(int, sp);
-    { const uint64_t mL = members; LANES({ acc[I_] = ((mL >> LANE) & 1) ? outLen[I_] : 0; }) }
+    { const uint64_t mL = members; LANES({ acc[I_] = LANE_IN(mL) ? outLen[I_] : 0; }) }
     SCAN_INCL(acc);
     {
         const uint64_t mL = members;
         LANES({
-            outStart[I_] = (int)op0 + acc[I_] - (((mL >> LANE) & 1) ? outLen[I_] : 0);
+            outStart[I_] = (int)op0 + acc[I_] - (LANE_IN(mL) ? outLen[I_] : 0);
             sp[I_]       = outStart[I_] + (ll[I_] & 0xFFFF) - off[I_];                     // where the match bytes come from
         })
         // a source before the start of the output is the sequential step's business (error, or a dictionary);
         // and the batch's output stays inside the room the caller checked
         // (LDS staging: a long match whose source starts before the staged tail and runs into this batch's output as well)
-        const uint64_t stop = BALLOT(((mL >> LANE) & 1) && (sp[I_] < 0 || acc[I_] > 1024 ||
+        const uint64_t stop = BALLOT(LANE_IN(mL) && (sp[I_] < 0 || acc[I_] > 1024 ||
                                      (kLds && coop[I_] && sp[I_] < op0 - kDecTail && (int64_t)sp[I_] + ml[I_] > op0)));
         if (stop) members &= (1ull << ctz64(stop)) - 1;
     }
@@ -1401,7 +1401,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         LV(uint32_t, g0); LV(uint32_t, g1); LV(uint32_t, g2); LV(uint64_t, g3);
         auto put_pieces = [&](const uint64_t who) {
             LANES({
-                const bool on = (who >> LANE) & 1;
+                const bool on = LANE_IN(who);
                 const int len = on ? ml[I_] : 0, at = on ? mdst[I_] : (int)kDecDump;
                 st32u(lb + at, g0[I_]);
                 st32u(lb + at + max_(len - 4, 0), g1[I_]);
@@ -1412,7 +1412,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
         // far matches: their bytes are requested from memory first ...
         LANES({
             g0[I_] = 0; g1[I_] = 0; g2[I_] = 0; g3[I_] = 0;
-            if ((far >> LANE) & 1) {
+            if (LANE_IN(far)) {
                 const uint8_t* q = dst + sp[I_]; const int len = ml[I_];
                 g0[I_] = ld32u(q); g1[I_] = ld32u(q + len - 4); g2[I_] = ld32u(q + max_(len - 8, 0)); g3[I_] = ld64u(q + 4);
             }
@@ -1448,7 +1448,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
                 STAT(8, 1);
                 const uint64_t go = pend & ~coopM & BALLOT(qoff[I_] + ml[I_] <= lo);
                 LANES({
-                    if ((go >> LANE) & 1) {
+                    if (LANE_IN(go)) {
                         const uint8_t* q = lb + qoff[I_]; const int len = ml[I_];
                         g0[I_] = ld32u(q); g1[I_] = ld32u(q + len - 4); g2[I_] = ld32u(q + max_(len - 8, 0)); g3[I_] = ld64u(q + 4);
                     }
@@ -1483,7 +1483,7 @@ DEV int wave_decode_plain_batch(const uint8_t* __restrict__ src, uint8_t* __rest
     }
     auto copy_matches = [&](const uint64_t who) {
         LANES({
-            if ((who >> LANE) & 1) {
+            if (LANE_IN(who)) {
                 const uint8_t* s = dst + sp[I_];
                 uint8_t*       d = dst + outStart[I_] + (ll[I_] & 0xFFFF);
                 const v16u_t a = *(const v16u_t*)s;

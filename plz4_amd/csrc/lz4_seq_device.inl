@@ -276,7 +276,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 Send = mm ? 64 : min_(64, lim0 + 1);
                 const uint64_t mmL = mm; const int SendL = Send;
                 LV(int, stA);
-                LANES({ stA[I_] = ((mmL >> LANE) & 1) ? eLane[I_] : 0; })
+                LANES({ stA[I_] = LANE_IN(mmL) ? eLane[I_] : 0; })
                 SCAN_MAX_EXCL(stA);
                 const uint64_t hasPm = BALLOT(stA[I_] > 0);
                 LANES({ stA[I_] = stA[I_] > 0 ? stA[I_] : cur0; })                // where probing resumed before me
@@ -323,7 +323,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 Send = mm ? 64 : min_(64, lim0 + 1);
                 const uint64_t mmL = mm; const int SendL = Send;
                 LV(int, stA);
-                LANES({ stA[I_] = ((mmL >> LANE) & 1) ? eLane[I_] : 0; })
+                LANES({ stA[I_] = LANE_IN(mmL) ? eLane[I_] : 0; })
                 SCAN_MAX_EXCL(stA);
                 const uint64_t hasPm = BALLOT(stA[I_] > 0);
                 LANES({ stA[I_] = stA[I_] > 0 ? stA[I_] : cur0; })
@@ -341,7 +341,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 const unsigned long long tc0 = STAT_NOW(); (void)tc0;
                 const uint64_t EL = E;
                 // (a lane that is not executed exchanges a 0: the slot stays as it is)
-                LANES({ rent[I_] = lds_max_rtn(&T[cur[I_].h], ((EL >> LANE) & 1) ? cur[I_].ent : 0u); })
+                LANES({ rent[I_] = lds_max_rtn(&T[cur[I_].h], LANE_IN(EL) ? cur[I_].ent : 0u); })
                 committed = EL;
                 const uint64_t upd = probes & BALLOT(rent[I_] != ce[I_]);
                 // (ascending lane order of the atomics on one slot is what makes the returned entry the sequential one: any other
@@ -352,7 +352,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 uint64_t diff = 0;
                 if (upd) {                   // (about half of the batches on text: worth the one conditional)
                     LANES({
-                        const bool u = (upd >> LANE) & 1;
+                        const bool u = LANE_IN(upd);
                         ce[I_] = u ? rent[I_] : ce[I_];
                         const int t = (int)(ce[I_] >> sh) - base;               // the lane of this batch whose position that is
                         const bool same = ce[I_] == cur[I_].pk;
@@ -365,7 +365,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                     // (a window that compares equal to its end says nothing about the length behind it: that one is measured again)
                     diff = upd & BALLOT((hitN[I_] != hit[I_]) | (fwdN[I_] != fwd[I_]) | (fwdN[I_] == 16));
                     LANES({
-                        const bool u = (upd >> LANE) & 1;
+                        const bool u = LANE_IN(upd);
                         hit[I_] = u ? hitN[I_] : hit[I_]; fwd[I_] = u ? fwdN[I_] : fwd[I_]; eLane[I_] = LANE + kMinMatch + fwd[I_];
                     })
                 }
@@ -380,21 +380,21 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                     for (int round = 1; !giveUp; ++round) {
                         {                                                      // take the last round's commits back
                             const uint64_t cm = committed;
-                            LANES({ if ((cm >> LANE) & 1) lds_min(&T[cur[I_].h], rent[I_]); })   // min over a slot's group == its pre-batch value
+                            LANES({ if (LANE_IN(cm)) lds_min(&T[cur[I_].h], rent[I_]); })   // min over a slot's group == its pre-batch value
                             LDS_ORDER();
                             committed = 0;
                         }
                         if (round == 4) { giveUp = true; break; }
                         walk();
                         const uint64_t EL2 = E;
-                        LANES({ if ((EL2 >> LANE) & 1) rent[I_] = lds_max_rtn(&T[cur[I_].h], cur[I_].ent); })
+                        LANES({ if (LANE_IN(EL2)) rent[I_] = lds_max_rtn(&T[cur[I_].h], cur[I_].ent); })
                         committed = EL2;
                         const uint64_t upd2 = probes & BALLOT(rent[I_] != ce[I_]);
                         if (EL2 & BALLOT((rent[I_] >> sh) >= (uint32_t)(base + LANE))) { EMU_CNT(2, 1); giveUp = true; break; }
                         if (!upd2) break;                                      // every probe read what it had assumed
                         if (upd2 & BALLOT(rent[I_] != cur[I_].pk && (rent[I_] >> sh) < (uint32_t)base)) { EMU_CNT(7, 1); giveUp = true; break; }
                         LANES({
-                            if ((upd2 >> LANE) & 1) ce[I_] = rent[I_];
+                            if (LANE_IN(upd2)) ce[I_] = rent[I_];
                             const int t = (int)(ce[I_] >> sh) - base;
                             const bool same = ce[I_] == cur[I_].pk;
                             for (int k = 0; k < 5; ++k) {
@@ -405,14 +405,14 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                         compare(Wn, hitN, fwdN);
                         const uint64_t diff2 = upd2 & BALLOT(hitN[I_] != hit[I_] || fwdN[I_] != fwd[I_] || fwdN[I_] == 16);
                         if (!diff2) break;                                     // same walk, same executed set: only offsets moved
-                        LANES({ if ((upd2 >> LANE) & 1) { hit[I_] = hitN[I_]; fwd[I_] = fwdN[I_]; eLane[I_] = LANE + kMinMatch + fwdN[I_]; } })
+                        LANES({ if (LANE_IN(upd2)) { hit[I_] = hitN[I_]; fwd[I_] = fwdN[I_]; eLane[I_] = LANE + kMinMatch + fwdN[I_]; } })
                     }
                 }
             }
             if (giveUp) {
                 if (committed) {
                     const uint64_t cm = committed;
-                    LANES({ if ((cm >> LANE) & 1) lds_min(&T[cur[I_].h], rent[I_]); })
+                    LANES({ if (LANE_IN(cm)) lds_min(&T[cur[I_].h], rent[I_]); })
                 }
                 LDS_FENCE();
                 return kGridGeneric;
@@ -439,7 +439,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 // (every lane stores: the ones without a match into the dump entry behind the block's last possible record)
                 const uint64_t mmL = mm; const int at = nseq;
                 LANES({
-                    const int slot = ((mmL >> LANE) & 1) ? at + LANE_RANK(mmL) : seqDump;
+                    const int slot = LANE_IN(mmL) ? at + LANE_RANK(mmL) : seqDump;
                     seq[slot] = seq_pack((uint32_t)(base + LANE), (uint32_t)fwd[I_], (uint32_t)(base + LANE) - (ce[I_] >> sh));
                 })
                 nseq += __builtin_popcountll(mm);

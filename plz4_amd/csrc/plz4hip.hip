@@ -86,6 +86,9 @@ struct CodecArgs {
     // the staged level-1 call writing its records back to back (plz4hip_dev_encode_body): dst = the frame body, bodyOff[i] = where
     // record i starts (made by the call: the scan over the records' lengths), bodyCap = the body's room
     int64_t*        bodyOff;    int64_t bodyCap;
+    // the staged level-1 parse tells when its block queue has run dry (its last blocks are under way, workgroups begin to leave):
+    // gate <- max(gate, gateSeq); the parse of the next call on ANOTHER stream waits for that behind k_parse_gate (launch_l1)
+    uint32_t*       gate;       uint32_t gateSeq;
     const int64_t*  dxSrcOff;   const int32_t* dxLen;                       // records: where a block's payload starts in src and its size (-1: not this path's)
     int32_t*        dxHashBad;                                              // records: the payload's xxh32 does not match (k_dx_rec_hash)
 };
@@ -166,6 +169,17 @@ __device__ __forceinline__ void l1_parse_loop(const CodecArgs& a, uint32_t* lds)
         if (n >= 0 && n <= a.l1MaxLen)
             nseq = wave_parse_l1(a.src + (int64_t)gi * a.srcStride, n, lds, a.l1Seq + (int64_t)i * a.l1SeqStride, &lastAnchor);
         if ((threadIdx.x & 63u) == 0) { SeqInfo inf; inf.nseq = nseq; inf.lastAnchor = lastAnchor; inf.total = 0; inf.stored = 0; a.l1Info[i] = inf; }
+    }
+    if (a.gate && (threadIdx.x & 63u) == 0) atomicMax(a.gate, a.gateSeq);    // (sequence numbers: launch_l1 starts over before they wrap)
+}
+// One wave that holds its stream back until the parse launch `want` has run its queue dry (or ~1.5 s have passed: never a hang).
+// Two parse launches started together share the CUs half and half and stay in step from then on -- nothing of one call then runs
+// beside the other's parse; behind this gate the second one moves into the CUs as the first one's workgroups leave them.
+__global__ __launch_bounds__(64) void k_parse_gate(const uint32_t* gate, uint32_t want)
+{
+    for (int it = 0; it < 400000; ++it) {
+        if ((int32_t)(__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) >= 0) break;
+        __builtin_amdgcn_s_sleep(127);
     }
 }
 template <int W> __global__ __launch_bounds__(64 * W) void k_l1_parse(CodecArgs a)
@@ -1277,6 +1291,12 @@ struct plz4hip_ctx {
     static constexpr int kL1Shared = 2;
     L1Ws         l1[kL1Shared];
     hipEvent_t   l1Done[kL1Shared] = {nullptr, nullptr}; hipStream_t l1Stream[kL1Shared] = {nullptr, nullptr}; bool l1Pending[kL1Shared] = {false, false};
+    // The parse kernel of a staged call fills the device by itself (persistent workgroups around all of a CU's LDS).  Two of them
+    // started together on two streams share the CUs half and half and stay in step, so that nothing of one call runs beside the
+    // other's parse.  They are therefore ordered on the device: a call's parse on another stream than the last one's waits (behind
+    // k_parse_gate) until that one has run its queue dry; it then moves into the CUs as the first one's workgroups leave, and the
+    // emit kernels of the first call run beside it.
+    uint32_t*    d_gate = nullptr; uint32_t gateSeq = 0; hipStream_t gateStream = nullptr; bool gatePending = false;
     // levels 3..11 on independent blocks: the list builder of the next group of blocks runs on this stream beside the walk of the
     // current one (launch_hc)
     hipStream_t  hcBuildStream = nullptr; hipEvent_t evHcFork = nullptr, evHcHist = nullptr, evHcChain[2] = {nullptr, nullptr}, evHcFree[2] = {nullptr, nullptr};
@@ -1928,6 +1948,17 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         const int ng = nb - g0 < per ? nb - g0 : per;
         a.blk0 = g0; a.nBlocks = ng;
         a.queue = next_queue(c, s, &e); HIPCHK(c, e);
+        const bool signals = !mid;                                              // (the level-1 parse and the duplex launch)
+        if (signals) {
+            if (c->gatePending && c->gateStream != s) hipLaunchKernelGGL(k_parse_gate, dim3(1), dim3(64), 0, s, (const uint32_t*)c->d_gate, c->gateSeq);
+            if (c->gateSeq >= 0x7FFF0000u) {                                    // (once in two billion launches: start over)
+                HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipMemset(c->d_gate, 0, sizeof(uint32_t))); c->gateSeq = 0;
+            }
+            a.gate = c->d_gate; a.gateSeq = ++c->gateSeq;
+            c->gatePending = true; c->gateStream = s;
+        } else {
+            a.gate = nullptr; c->gatePending = false;
+        }
         if (mid && a.hcPfx) hipLaunchKernelGGL(k_hc_mid<true>, dim3(grid_for(ng, c->hcWaves)), dim3(64), 0, s, a);
         else if (mid) hipLaunchKernelGGL(k_hc_mid<false>, dim3(grid_for(ng, c->hcWaves)), dim3(64), 0, s, a);
         else if (rider && g0 == 0) {
@@ -2101,6 +2132,8 @@ int plz4hip_ctx_create(int device, plz4hip_ctx** out)
     hipError_t e = dg.err;
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_queues, kQueueSlots * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->d_gate, 256);
+    if (e == hipSuccess) e = hipMemset(c->d_gate, 0, 256);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device);
     int encPer = 0, decPer = 0;
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&encPer, k_encode_rec<kEncWavesPerWg>, 64 * kEncWavesPerWg, 0);
@@ -2145,6 +2178,7 @@ void plz4hip_ctx_destroy(plz4hip_ctx* c)
     if (c->d_lenCopy) hipFree(c->d_lenCopy);
     if (c->d_hcPfx) hipFree(c->d_hcPfx);
     if (c->lenDone) hipEventDestroy(c->lenDone);
+    if (c->d_gate) hipFree(c->d_gate);
     if (c->hcDone) hipEventDestroy(c->hcDone);
     if (c->hashStream) { hipStreamSynchronize(c->hashStream); hipStreamDestroy(c->hashStream); }
     if (c->hcBuildStream) { hipStreamSynchronize(c->hcBuildStream); hipStreamDestroy(c->hcBuildStream); }

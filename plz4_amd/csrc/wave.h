@@ -33,6 +33,7 @@
 #define WL(x, w, v)    do { const auto wl_v_ = (v); (x)[(w)] = wl_v_; } while (0)   /* write one lane (uniform lane index) */
 #define SHFL(x, l)     ((x)[(l) & 63])                  /* read another lane's value (per-lane lane index) */
 #define UNI(x)         (x)
+#define LANE_IN(mask)  ((((uint64_t)(mask)) >> lane_) & 1ull)   /* is this lane in a wave-uniform 64-bit mask */
 #define LVREF(T, x)    T (&x)[64]                       /* a per-lane variable as a function parameter */
 #define SCAN_INCL(x)   do { for (int s_ = 1; s_ < 64; ++s_) (x)[s_] += (x)[s_ - 1]; } while (0)   /* inclusive prefix sum over lanes */
 /* x[l] <- max of x over the lanes strictly below l (0 for lane 0); x >= 0 */
@@ -62,6 +63,9 @@ static inline int plz4_emu_step()  { return plz4_emu_descending ? -1 : 1; }
 #define WL(x, w, v)    do { const auto wl_v_ = (v); (x)[0] = (LANE == (w)) ? wl_v_ : (x)[0]; } while (0)
 #define SHFL(x, l)     plz4_bpermute((x)[0], (l))
 #define UNI(x)         plz4_readfirstlane((x))
+// a wave-uniform 64-bit mask as a per-lane condition: the scalar register pair itself is the select / exec mask, where
+// ((mask >> LANE) & 1) costs two v_and and a 64-bit v_cmp
+#define LANE_IN(mask)  (__builtin_amdgcn_inverse_ballot_w64((uint64_t)(mask)))
 #define LVREF(T, x)    T (&x)[1]
 #define SCAN_INCL(x)   do { (x)[0] = plz4_scan_incl((x)[0]); } while (0)
 #define SCAN_MAX_EXCL(x) do { (x)[0] = plz4_scan_max_excl((x)[0]); } while (0)
