@@ -24,7 +24,9 @@
  * calling thread's own copy of the text (valid until that thread asks again).
  * Memory: the host-buffer calls keep their pinned host + device staging (up to 3 chunks of <= 4 GiB; one of <= 12 GiB at the HC
  * levels, which run a chunk at a time), level 1 its sequence records (2.25 bytes per input byte of the largest group of blocks
- * in one call, at most half of what is free: PLZ4HIP_L1_BUDGET_GIB) and the HC levels their workspaces between calls;
+ * in one call, at most half of what is free: PLZ4HIP_L1_BUDGET_GIB; a second such workspace when calls arrive on a second stream
+ * while the first one is busy, so that the two need not wait for each other -- PLZ4HIP_L1_WORKSPACES=1: never) and the HC levels
+ * their workspaces between calls;
  * plz4hip_ctx_trim gives them back.  The HC workspaces are sized by the call: on independent blocks levels 3..11 keep 14.5 bytes
  * per input byte of the blocks in flight (chain, per-hash lists, sequence records of the segments), level 12 22.5 (the search results as well), level 2 2.25, out
  * of a quarter of the device memory that is free when the call arrives, at most 64 GiB; a call whose blocks do not fit runs in
@@ -259,7 +261,11 @@ int plz4hip_dev_duplex_body(plz4hip_ctx* ctx, const void* src, int64_t srcBytes,
  * gets per-block errors, not slower output: pass 0 rather than a guess.
  * The staged level-1 call and the HC levels (here and in plz4hip_dev_encode_records) work in per-ctx workspaces and read a
  * per-ctx sanitised copy of srcLen: jobs enqueued on different streams of one ctx are ordered behind each other on the device
- * (an event wait, no host block); they never overlap. */
+ * (an event wait, no host block); they never overlap.  The exception is the staged level-1 call on device-resident records
+ * (plz4hip_dev_encode_records / _encode_body / _duplex_records / _duplex_body): a ctx keeps two record workspaces, so calls that
+ * alternate over two streams overlap -- the parse launch of the later call waits on the device until the earlier one has handed
+ * out its last block (the parse fills the chip by itself), then moves in as that one's workgroups leave, and the earlier call's
+ * emit kernels run beside it (bench.py --pipelines: + 10 % over one stream). */
 int plz4hip_dev_compress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
                          void* dst, int64_t dstStride, const int32_t* dstCap, int level, int maxLen, int32_t* result, void* stream);
 int plz4hip_dev_decompress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,

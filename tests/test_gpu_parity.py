@@ -587,6 +587,64 @@ def test_gpu_dev_compress_on_two_streams_of_one_ctx(ref, orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nstreams", [2, 3])
+def test_gpu_duplex_body_calls_alternating_over_streams_of_one_ctx(orc, nstreams):
+    """The bench's pipelines in small: plz4hip_dev_duplex_body calls of DIFFERENT batches enqueued back to back on two (three)
+    streams of one ctx -- the ctx has two record workspaces, the parse of a call waits on the device behind k_parse_gate for the
+    parse before it, the emit kernels of one call run beside the parse of the next (a third stream shares a workspace: ordered by
+    an event).  Every call's frame body must be its own batch's records (blk.CompressToBlk, blk/blk.go:69-109) and every decode
+    side the plaintext of the body the same stream's call before it wrote."""
+    import torch
+    from plz4_amd._native import Engine
+    e = Engine(0)
+    bsz = 1 << 20
+    dev = torch.device("cuda:0")
+    rounds = 3
+    pipes = []
+    for p in range(nstreams):
+        batches = []
+        for r in range(rounds + 1):
+            kind = "TMT"[(p + r) % 3]
+            data = synth.make(kind, (40 + 7 * p + 3 * r) * bsz + 1234 * (r + 1), bsz)
+            data = np.roll(data, 1000 * (p * 5 + r) + 17)
+            recs = [orc.block_record(data[o:o + bsz], bsz, True) for o in range(0, data.size, bsz)]
+            batches.append({"data": data, "d_src": torch.from_numpy(data).to(dev), "want": np.concatenate(recs), "nb": len(recs)})
+        cap = max(b["want"].size for b in batches) + 64
+        nbmax = max(b["nb"] for b in batches)
+        pipes.append({"batches": batches, "stream": torch.cuda.Stream(device=dev),
+                      "bodies": [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(rounds + 1)],
+                      "offs": [torch.zeros(nbmax + 1, dtype=torch.int64, device=dev) for _ in range(rounds + 1)],
+                      "lens": [torch.zeros(nbmax, dtype=torch.int32, device=dev) for _ in range(rounds + 1)],
+                      "outs": [torch.zeros(nbmax * bsz, dtype=torch.uint8, device=dev) for _ in range(rounds + 1)],
+                      "res": [torch.zeros(nbmax, dtype=torch.int32, device=dev) for _ in range(rounds + 1)],
+                      "st": [torch.full((nbmax,), -9, dtype=torch.int32, device=dev) for _ in range(rounds + 1)]})
+    torch.cuda.synchronize()
+    for r in range(rounds + 1):                       # every call of a round is enqueued before anything is waited for
+        for pp in pipes:
+            b = pp["batches"][r]; s = pp["stream"].cuda_stream
+            if r == 0:
+                e.dev_encode_body(b["d_src"].data_ptr(), b["data"].size, bsz, True, pp["bodies"][0].data_ptr(), pp["bodies"][0].numel(),
+                                  pp["offs"][0].data_ptr(), pp["lens"][0].data_ptr(), s, level=1)
+            else:
+                prev = pp["batches"][r - 1]
+                e.dev_duplex_body(b["d_src"].data_ptr(), b["data"].size, bsz, True, pp["bodies"][r].data_ptr(), pp["bodies"][r].numel(),
+                                  pp["offs"][r].data_ptr(), pp["lens"][r].data_ptr(),
+                                  pp["bodies"][r - 1].data_ptr(), pp["offs"][r - 1].data_ptr(), prev["nb"], bsz, True,
+                                  pp["outs"][r].data_ptr(), bsz, bsz, pp["res"][r].data_ptr(), pp["st"][r].data_ptr(), s)
+    torch.cuda.synchronize()
+    for p, pp in enumerate(pipes):
+        for r in range(rounds + 1):
+            b = pp["batches"][r]
+            assert int(pp["offs"][r][b["nb"]].item()) == b["want"].size, (p, r)
+            assert np.array_equal(pp["bodies"][r][:b["want"].size].cpu().numpy(), b["want"]), (p, r)
+            if r > 0:
+                prev = pp["batches"][r - 1]
+                assert int(pp["st"][r][:prev["nb"]].abs().sum().item()) == 0, (p, r)
+                assert np.array_equal(pp["outs"][r][:prev["data"].size].cpu().numpy(), prev["data"]), (p, r)
+    e.close()
+
+
+@pytest.mark.gpu
 def test_gpu_bench_modes_run_on_one_gpu():
     """bench.py's other code paths on the one GPU of the box: the N > 1 path (process group, gather stream, size all-gather,
     interleave on rank 0) with a single rank (PLZ4_BENCH_FORCE_GATHER), and the decode-only mode of configs[2]."""
