@@ -552,11 +552,42 @@ def main():
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step_decode() if args.decode_only else (step_duplex() if duplex else step())
+    pipe_check = None
     if duplex and len(pipes) > 1:
         # (untimed, whatever --warmup says: every further pipeline makes one call, which also puts its record workspace in place)
         torch.cuda.synchronize()
         while calls["n"] % len(pipes) != 0 or calls["n"] < len(pipes):
             step_duplex()
+        torch.cuda.synchronize()
+
+        # Still untimed: do the pipelines pay on this process's streams?  Calls over several streams overlap only if the runtime
+        # has put the streams on different hardware queues and the launches stay staggered; about one process in seven was seen
+        # to run them at 495 ms per step instead of 304 (every step of the run, the serial steps after it at their usual speed).
+        # So a few steps are clocked both ways before the timed region; a set of streams that does not pay is replaced once, and
+        # if the new one does not pay either the timed steps run on one stream (config.pipelines says what ran).
+        def clock(ps, n):
+            keep = list(pipes); pipes[:] = ps
+            torch.cuda.synchronize(); t_ = time.perf_counter()
+            for _ in range(n): step_duplex()
+            torch.cuda.synchronize(); dt_ = (time.perf_counter() - t_) / n
+            pipes[:] = keep
+            return dt_
+        one = clock(pipes[:1], 2)
+        both = clock(pipes, 2 * len(pipes))
+        tries = 0
+        force_bad = int(os.environ.get("PLZ4_BENCH_TEST_PIPE_CHECK", "0"))       # (tests: pretend the first N checks fail)
+        while (both > 0.97 * one or tries < force_bad) and tries < 2:
+            tries += 1
+            if tries == 1:
+                for pt_ in pipes: pt_["stream"] = torch.cuda.Stream(device=dev)
+                both = clock(pipes, 2 * len(pipes))
+            else:
+                log("rank %d: %d streams do not pay here (%.1f ms per step against %.1f on one): the timed steps run on one stream" % (rank, len(pipes), both * 1e3, one * 1e3))
+                del pipes[1:]; NPIPE = 1; pt_ = None
+                torch.cuda.synchronize(); torch.cuda.empty_cache()
+        pipe_check = {"one_stream_ms": round(one * 1e3, 1), "pipelined_ms": round(both * 1e3, 1), "streams_replaced": tries}
+        log("rank %d: pipeline check, ms per step: one stream %.1f, %d streams %.1f%s" % (rank, one * 1e3, NPIPE, both * 1e3, " (streams replaced)" if tries else ""))
+        calls["n"] = 0
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -604,6 +635,7 @@ def main():
     # ms per step, summed over the parts: encode kernel, scan+compact, gather, decode kernel (decode overlaps the next encode)
     seg = np.array([[sum(e[0].elapsed_time(e[1]) for e in st_), sum(e[1].elapsed_time(e[2]) for e in st_),
                      sum(e[2].elapsed_time(e[3]) for e in st_), sum(e[4].elapsed_time(e[5]) for e in st_)] for st_ in evs])
+    log("rank %d: call begin-to-end on its stream, ms per step: %s" % (rank, " ".join("%.1f" % x for x in seg[:, 0])))
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if multi:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
@@ -684,6 +716,7 @@ def main():
                 "step is one full encode and one full decode, the last body is decoded and checked after the timed region) -> frame body")
             out["config"]["duplex"] = True
             out["config"]["pipelines"] = NPIPE
+            if pipe_check: out["config"]["pipeline_check"] = pipe_check
             if NPIPE > 1:
                 out["config"]["workload"] = out["config"]["workload"].replace(
                     "the frame body the previous step produced", "the frame body the same stream's previous call produced (the steps alternate "

@@ -117,8 +117,13 @@ struct GStage { Win20 P; Win20 C; uint32_t h, ent, pk; };     // window, candida
 #endif
 enum { P_BATCH = 0, P_CYC_MEM, P_CYC_LDS, P_CYC_REFRESH, P_CYC_CMP, P_CYC_WALK, P_CYC_TAIL, P_REPAIR, P_PRIME, P_GENERIC, P_CYC_TOTAL, P_BLOCKS, P_SEQ, P_CYC_GEN, P_CYC_NH, P_CYC_HOP, P_CYC_E, P_CYC_SLOW, P_HOPS };
 
-template <bool U16>
-DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab, uint64_t* __restrict__ seq, int* lastAnchor)
+// kLdsWin: the windows of the batches ahead come through `scr` (256 bytes of LDS owned by this wave) instead of one 20-byte load per
+// lane: the 64 windows of a batch are 83 consecutive bytes, but 64 overlapping per-lane loads are 128 accesses to the CU's vector
+// cache for them (its tag pipeline is what ten parser waves per CU saturate: TA busy 65 %, TCP stalled on pending misses 46 % of
+// the time, profiles/r04b_ta_counters.txt).  The lanes fetch consecutive dwords a batch earlier (one coalesced load), park them in
+// LDS and every lane reads its 20 bytes back from its byte offset.
+template <bool U16, bool kLdsWin = false>
+DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab, uint64_t* __restrict__ seq, int* lastAnchor, uint8_t* scr = nullptr)
 {
     const int      sh      = U16 ? 0 : 10;
     const uint32_t tagMask = (1u << sh) - 1u;
@@ -143,6 +148,8 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
         int  width   = 16;                         // generic batches: 16 lanes first, 64 when a search drags on
         // the pipeline's three stages; which one is batch k-1 / k / k+1 rotates with the unrolled loop below
         LV(GStage, S0); LV(GStage, S1); LV(GStage, S2);
+        LV(uint32_t, pf);                              // kLdsWin: dword LANE of [base + 128, base + 384), requested a batch ago
+        LANES({ pf[I_] = 0; })
         LANES({ for (int k = 0; k < 5; ++k) { S0[I_].P.w[k] = 0; S0[I_].C.w[k] = 0; } S0[I_].h = 0; S0[I_].ent = 0; S0[I_].pk = 0; S1[I_] = S0[I_]; S2[I_] = S0[I_]; })
         enum { kGridNext = 0, kGridDone = 1, kGridGeneric = 2, kGridStop = 3 };
 
@@ -206,8 +213,20 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 const uint32_t q1 = (uint32_t)(base + 64 + LANE), pr = next[I_].pk >> sh;
                 const bool pc = (pr < q1) & (pr + kMaxDist >= q1) & (((next[I_].pk ^ next[I_].ent) & tagMask) == 0);
                 next[I_].C = load_win20(src, (int)(pc ? pr : q1));
-                prev[I_].P = load_win20(src, base + 128 + LANE);
+                if (!kLdsWin) prev[I_].P = load_win20(src, base + 128 + LANE);
             })
+            if (kLdsWin) {
+                // the window of batch k+2 out of the dwords requested a batch ago; the dwords of batch k+3 on their way
+                LANES({ ((uint32_t*)scr)[LANE] = pf[I_]; })
+                LDS_ORDER();
+                LANES({
+                    const v16u_t a = *(const v16u_t*)(scr + LANE);
+                    prev[I_].P.w[0] = a.w[0]; prev[I_].P.w[1] = a.w[1]; prev[I_].P.w[2] = a.w[2]; prev[I_].P.w[3] = a.w[3];
+                    prev[I_].P.w[4] = ld32u(scr + LANE + 16);
+                })
+                LDS_ORDER();
+                LANES({ pf[I_] = ld32u(src + min_(base + 192 + 4 * LANE, n - 4)); })
+            }
             const unsigned long long ts3 = STAT_NOW(); (void)ts3;
             STAT(P_CYC_CMP, ts3 - ts2);
 
@@ -484,6 +503,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                         const uint32_t q0 = (uint32_t)(base + LANE), pr = S0[I_].pk >> sh;
                         const bool pc = pr < q0 && pr + kMaxDist >= q0 && ((S0[I_].pk ^ S0[I_].ent) & tagMask) == 0;
                         S0[I_].C = load_win20(src, (int)(pc ? pr : q0));
+                        if (kLdsWin) pf[I_] = ld32u(src + min_(base + 128 + 4 * LANE, n - 4));
                     })
                     LDS_ORDER();
                     int rc;
@@ -600,10 +620,11 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
 }
 
 // LZ4_compress_fast_extState's table choice (lz4.c:1389): byU16 below 64 KiB + 11
-DEV int wave_parse_l1(const uint8_t* __restrict__ src, int n, void* tab, uint64_t* __restrict__ seq, int* lastAnchor)
+template <bool kLdsWin = false>
+DEV int wave_parse_l1(const uint8_t* __restrict__ src, int n, void* tab, uint64_t* __restrict__ seq, int* lastAnchor, uint8_t* scr = nullptr)
 {
     if (n < k64KLimit) return wave_parse_l1_tt<true>(src, n, tab, seq, lastAnchor);
-    return wave_parse_l1_tt<false>(src, n, tab, seq, lastAnchor);
+    return wave_parse_l1_tt<false, kLdsWin>(src, n, tab, seq, lastAnchor, scr);
 }
 
 // ------------------------------------------------------------------------------------------ EMIT

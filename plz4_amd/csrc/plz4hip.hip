@@ -160,14 +160,15 @@ template <int W> __global__ __launch_bounds__(64 * W) void k_encode_rec(CodecArg
 // ---- level 1 in stages (independent blocks up to 4 MiB, no dictionary): lz4_seq_device.inl ------------------------------------
 // k_l1_parse: persistent, one wave per block, the hash table in LDS -- the only serial stage; it writes one 8-byte record per
 // sequence.  The others are plain data-parallel kernels, one lane per sequence, any number of waves per block, no LDS.
-__device__ __forceinline__ void l1_parse_loop(const CodecArgs& a, uint32_t* lds)
+template <bool kLdsWin = false>
+__device__ __forceinline__ void l1_parse_loop(const CodecArgs& a, uint32_t* lds, uint8_t* scr = nullptr)
 {
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
         const int gi = a.blk0 + i;
         const int n  = block_len(a, gi);
         int lastAnchor = 0, nseq = -1;                                       // -1: a block the workspace was not sized for
         if (n >= 0 && n <= a.l1MaxLen)
-            nseq = wave_parse_l1(a.src + (int64_t)gi * a.srcStride, n, lds, a.l1Seq + (int64_t)i * a.l1SeqStride, &lastAnchor);
+            nseq = wave_parse_l1<kLdsWin>(a.src + (int64_t)gi * a.srcStride, n, lds, a.l1Seq + (int64_t)i * a.l1SeqStride, &lastAnchor, scr);
         if ((threadIdx.x & 63u) == 0) { SeqInfo inf; inf.nseq = nseq; inf.lastAnchor = lastAnchor; inf.total = 0; inf.stored = 0; a.l1Info[i] = inf; }
     }
     if (a.gate && (threadIdx.x & 63u) == 0) atomicMax(a.gate, a.gateSeq);    // (sequence numbers: launch_l1 starts over before they wrap)
@@ -1130,7 +1131,8 @@ __global__ __launch_bounds__(64) void k_decode_rec_dx(CodecArgs a)
 // Each role pulls block ids from its own queue until it is empty; the waves of a workgroup never synchronise.
 // (P parser waves + D decoder waves per workgroup: experiment switch PLZ4HIP_DUPLEX="P,D"; PRIO: the parser waves' s_setprio,
 // PLZ4HIP_DUPLEX_PRIO)
-constexpr int duplex_wgs_per_cu(int P, int D) { return (160 * 1024) / (P * kHashBytes + D * kDecLdsBytes); }
+constexpr int kWinScratch = 256;          // per parser wave: the dwords its lanes park for the windows of the batch after next
+constexpr int duplex_wgs_per_cu(int P, int D) { return (160 * 1024) / (P * (kHashBytes + kWinScratch) + D * kDecLdsBytes); }
 #if defined(PLZ4_EXP_DUPLEX_EU)
 constexpr int duplex_waves_per_eu(int P, int D) { return PLZ4_EXP_DUPLEX_EU; }       // EXPERIMENT: forced occupancy target
 #else
@@ -1142,10 +1144,11 @@ void k_l1_duplex(CodecArgs a, CodecArgs d)
 {
     __shared__ uint32_t tabS[P][kHashBytes / 4];
     __shared__ __attribute__((aligned(16))) uint8_t dlS[D][kDecLdsBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t winS[P][kWinScratch];
     const int w = plz4_readfirstlane((int)(threadIdx.x >> 6));
     if (w < P) {
         if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
-        l1_parse_loop(a, tabS[w]);
+        l1_parse_loop<true>(a, tabS[w], winS[w]);
     } else {
         decode_rec_loop<false>(d, dlS[w - P]);
     }

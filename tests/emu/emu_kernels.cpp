@@ -32,6 +32,15 @@ int emu_encode_block_seq(const uint8_t* src, int n, uint8_t* dst, int cap, int* 
     uint64_t* seq = (uint64_t*)malloc(((size_t)seq_capacity(n) + 1) * 8);       // + the dump entry
     int lastAnchor = 0;
     const int nseq = wave_parse_l1(src, n, lds, seq, &lastAnchor);
+    {   // the duplex kernel's build of the parser (windows through an LDS scratch, lz4_seq_device.inl kLdsWin): same records
+        static thread_local uint8_t scr[256 + 64];
+        uint64_t* seq2 = (uint64_t*)malloc(((size_t)seq_capacity(n) + 1) * 8);
+        int lastAnchor2 = 0;
+        const int nseq2 = wave_parse_l1<true>(src, n, lds, seq2, &lastAnchor2, scr);
+        const bool same = nseq2 == nseq && lastAnchor2 == lastAnchor && (nseq <= 0 || memcmp(seq, seq2, (size_t)nseq * 8) == 0);
+        free(seq2);
+        if (!same) { free(seq); return -999998; }
+    }
     if (nseqOut) *nseqOut = nseq;
     const int nChunks = (nseq + kSeqChunk - 1) / kSeqChunk;
     uint32_t* cb = (uint32_t*)malloc((size_t)(nChunks + 1) * 4);
