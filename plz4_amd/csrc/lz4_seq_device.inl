@@ -73,6 +73,14 @@ DEV uint32_t eq_bytes(uint32_t x)                 // leading equal bytes of a dw
 {
     return (x ? (uint32_t)__builtin_ctz(x) : 32u) >> 3;                   // (v_ffbl_b32 + v_min_u32 32: no branch)
 }
+DEV uint32_t align_bytes(uint32_t hi, uint32_t lo, uint32_t bytes)      // bytes [bytes, bytes + 4) of the pair (lo, hi): v_alignbyte_b32
+{
+#if defined(PLZ4_EMU)
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (bytes & 3)));
+#else
+    return __builtin_amdgcn_alignbyte(hi, lo, bytes);
+#endif
+}
 DEV int win20_fwd(const Win20& p, const Win20& c)
 {
     const uint32_t b1 = eq_bytes(p.w[1] ^ c.w[1]), b2 = eq_bytes(p.w[2] ^ c.w[2]), b3 = eq_bytes(p.w[3] ^ c.w[3]), b4 = eq_bytes(p.w[4] ^ c.w[4]);
@@ -122,7 +130,7 @@ enum { P_BATCH = 0, P_CYC_MEM, P_CYC_LDS, P_CYC_REFRESH, P_CYC_CMP, P_CYC_WALK, 
 // cache for them (its tag pipeline is what ten parser waves per CU saturate: TA busy 65 %, TCP stalled on pending misses 46 % of
 // the time, profiles/r04b_ta_counters.txt).  The lanes fetch consecutive dwords a batch earlier (one coalesced load), park them in
 // LDS and every lane reads its 20 bytes back from its byte offset.
-template <bool U16, bool kLdsWin = false>
+template <bool U16, int kLdsWin = 0>
 DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab, uint64_t* __restrict__ seq, int* lastAnchor, uint8_t* scr = nullptr)
 {
     const int      sh      = U16 ? 0 : 10;
@@ -215,7 +223,19 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
                 next[I_].C = load_win20(src, (int)(pc ? pr : q1));
                 if (!kLdsWin) prev[I_].P = load_win20(src, base + 128 + LANE);
             })
-            if (kLdsWin) {
+            if (kLdsWin == 2) {
+                // (no LDS to spare -- ten tables fill the CU: the same through the lane-exchange network, six dwords from the lanes
+                // that hold them and a byte alignment each)
+                LV(uint32_t, g0); LV(uint32_t, g1); LV(uint32_t, g2); LV(uint32_t, g3); LV(uint32_t, g4); LV(uint32_t, g5);
+                LANES({ const int j = LANE >> 2; g0[I_] = SHFL(pf, j); g1[I_] = SHFL(pf, j + 1); g2[I_] = SHFL(pf, j + 2); g3[I_] = SHFL(pf, j + 3); g4[I_] = SHFL(pf, j + 4); g5[I_] = SHFL(pf, j + 5); })
+                LANES({
+                    const uint32_t sft = (uint32_t)(LANE & 3);
+                    prev[I_].P.w[0] = align_bytes(g1[I_], g0[I_], sft); prev[I_].P.w[1] = align_bytes(g2[I_], g1[I_], sft);
+                    prev[I_].P.w[2] = align_bytes(g3[I_], g2[I_], sft); prev[I_].P.w[3] = align_bytes(g4[I_], g3[I_], sft);
+                    prev[I_].P.w[4] = align_bytes(g5[I_], g4[I_], sft);
+                })
+                LANES({ pf[I_] = ld32u(src + min_(base + 192 + 4 * LANE, n - 4)); })
+            } else if (kLdsWin) {
                 // the window of batch k+2 out of the dwords requested a batch ago; the dwords of batch k+3 on their way
                 LANES({ ((uint32_t*)scr)[LANE] = pf[I_]; })
                 LDS_ORDER();
@@ -620,7 +640,7 @@ DEV int wave_parse_l1_tt(const uint8_t* __restrict__ src, const int n, void* tab
 }
 
 // LZ4_compress_fast_extState's table choice (lz4.c:1389): byU16 below 64 KiB + 11
-template <bool kLdsWin = false>
+template <int kLdsWin = 0>
 DEV int wave_parse_l1(const uint8_t* __restrict__ src, int n, void* tab, uint64_t* __restrict__ seq, int* lastAnchor, uint8_t* scr = nullptr)
 {
     if (n < k64KLimit) return wave_parse_l1_tt<true>(src, n, tab, seq, lastAnchor);

@@ -160,7 +160,7 @@ template <int W> __global__ __launch_bounds__(64 * W) void k_encode_rec(CodecArg
 // ---- level 1 in stages (independent blocks up to 4 MiB, no dictionary): lz4_seq_device.inl ------------------------------------
 // k_l1_parse: persistent, one wave per block, the hash table in LDS -- the only serial stage; it writes one 8-byte record per
 // sequence.  The others are plain data-parallel kernels, one lane per sequence, any number of waves per block, no LDS.
-template <bool kLdsWin = false>
+template <int kLdsWin = 0>
 __device__ __forceinline__ void l1_parse_loop(const CodecArgs& a, uint32_t* lds, uint8_t* scr = nullptr)
 {
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void k_parse_gate(const uint32_t* gate, uint32_
 template <int W> __global__ __launch_bounds__(64 * W) void k_l1_parse(CodecArgs a)
 {
     ENC_WAVE_TABLE(lds);
-    l1_parse_loop(a, lds);
+    l1_parse_loop<2>(a, lds);                  // (ten tables fill the CU's LDS: the windows through the lane exchange, lz4_seq_device.inl)
 }
 
 // grid (waves per block / 4, blocks of the group): bytes of every chunk of 1024 sequences.  kBack: the level-1 parser's records
@@ -1148,7 +1148,7 @@ void k_l1_duplex(CodecArgs a, CodecArgs d)
     const int w = plz4_readfirstlane((int)(threadIdx.x >> 6));
     if (w < P) {
         if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
-        l1_parse_loop<true>(a, tabS[w], winS[w]);
+        l1_parse_loop<1>(a, tabS[w], winS[w]);
     } else {
         decode_rec_loop<false>(d, dlS[w - P]);
     }

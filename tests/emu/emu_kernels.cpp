@@ -36,8 +36,10 @@ int emu_encode_block_seq(const uint8_t* src, int n, uint8_t* dst, int cap, int* 
         static thread_local uint8_t scr[256 + 64];
         uint64_t* seq2 = (uint64_t*)malloc(((size_t)seq_capacity(n) + 1) * 8);
         int lastAnchor2 = 0;
-        const int nseq2 = wave_parse_l1<true>(src, n, lds, seq2, &lastAnchor2, scr);
-        const bool same = nseq2 == nseq && lastAnchor2 == lastAnchor && (nseq <= 0 || memcmp(seq, seq2, (size_t)nseq * 8) == 0);
+        const int nseq2 = wave_parse_l1<1>(src, n, lds, seq2, &lastAnchor2, scr);
+        bool same = nseq2 == nseq && lastAnchor2 == lastAnchor && (nseq <= 0 || memcmp(seq, seq2, (size_t)nseq * 8) == 0);
+        const int nseq3 = wave_parse_l1<2>(src, n, lds, seq2, &lastAnchor2, nullptr);          // ... and through the lane exchange
+        same = same && nseq3 == nseq && lastAnchor2 == lastAnchor && (nseq <= 0 || memcmp(seq, seq2, (size_t)nseq * 8) == 0);
         free(seq2);
         if (!same) { free(seq); return -999998; }
     }
