@@ -681,3 +681,12 @@ def test_gpu_bench_modes_run_on_one_gpu():
         assert out.returncode == 0, out.stderr[-2000:]
         line = json.loads(out.stdout.strip().splitlines()[-1])
         assert line["value"] > 0 and line["config"]["pipelines"] == want and line["serial_step"]["value"] > 0
+        assert (want > 1) == ("pipeline_check" in line["config"])
+    # the check that clocks the pipelined steps against one stream before the timed region: its two ways out (new streams; one
+    # stream), forced
+    for forced, want in (("1", 2), ("2", 1)):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--blocks", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                             env=dict(os.environ, PLZ4_BENCH_TEST_PIPE_CHECK=forced), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = json.loads(out.stdout.strip().splitlines()[-1])
+        assert line["config"]["pipelines"] == want and line["config"]["pipeline_check"]["streams_replaced"] == int(forced)
