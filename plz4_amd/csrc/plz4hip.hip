@@ -1299,6 +1299,7 @@ struct plz4hip_ctx {
     // other's parse.  They are therefore ordered on the device: a call's parse on another stream than the last one's waits (behind
     // k_parse_gate) until that one has run its queue dry; it then moves into the CUs as the first one's workgroups leave, and the
     // emit kernels of the first call run beside it.
+    int          l1Refused = 0;                // calls left before a refused second workspace is asked for again
     uint32_t*    d_gate = nullptr; uint32_t gateSeq = 0; hipStream_t gateStream = nullptr; bool gatePending = false;
     // levels 3..11 on independent blocks: the list builder of the next group of blocks runs on this stream beside the walk of the
     // current one (launch_hc)
@@ -1905,6 +1906,18 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     const size_t perBlock  = sizeof(SeqInfo) + (size_t)maxChunks * 8 + seqStride * 9;
     const auto need_for = [&](int per) { return round_up((size_t)per * sizeof(SeqInfo), 256) + 2 * round_up((size_t)per * maxChunks * 4, 256) + (size_t)per * seqStride * 9; };
     int per = nb;
+    if (shared && !fused && wsi != 0 && !ws->d && c->l1Refused > 0) { c->l1Refused--; wsi = 0; ws = &c->l1[0]; }   // (refused a moment ago)
+    if (shared && !fused && wsi != 0 && !ws->d) {
+        // a SECOND workspace is there for overlap: it is taken whole or not at all (a smaller one would cut this call into groups,
+        // which costs more than waiting for the first workspace does)
+        if (hipMalloc((void**)&ws->d, need_for(nb)) == hipSuccess) ws->bytes = need_for(nb);
+        else {
+            (void)hipGetLastError();
+            ws->d = nullptr; ws->bytes = 0; wsi = 0; ws = &c->l1[0];
+            c->l1Refused = 8;                                                    // (the next calls do not ask again)
+            if (getenv("PLZ4HIP_VERBOSE")) fprintf(stderr, "plz4hip: level 1: no room for a second workspace of %zu MiB, sharing the first\n", need_for(nb) >> 20);
+        }
+    }
     if (!fused && need_for(nb) > ws->bytes) {
         size_t freeB = 0, totalB = 0;
         if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) return fail(c, PLZ4HIP_E_DEVICE, "hipMemGetInfo");

@@ -587,8 +587,8 @@ def test_gpu_dev_compress_on_two_streams_of_one_ctx(ref, orc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nstreams", [2, 3])
-def test_gpu_duplex_body_calls_alternating_over_streams_of_one_ctx(orc, nstreams):
+@pytest.mark.parametrize("nstreams,starve", [(2, False), (3, False), (2, True)])
+def test_gpu_duplex_body_calls_alternating_over_streams_of_one_ctx(orc, nstreams, starve):
     """The bench's pipelines in small: plz4hip_dev_duplex_body calls of DIFFERENT batches enqueued back to back on two (three)
     streams of one ctx -- the ctx has two record workspaces, the parse of a call waits on the device behind k_parse_gate for the
     parse before it, the emit kernels of one call run beside the parse of the next (a third stream shares a workspace: ordered by
@@ -619,6 +619,15 @@ def test_gpu_duplex_body_calls_alternating_over_streams_of_one_ctx(orc, nstreams
                       "res": [torch.zeros(nbmax, dtype=torch.int32, device=dev) for _ in range(rounds + 1)],
                       "st": [torch.full((nbmax,), -9, dtype=torch.int32, device=dev) for _ in range(rounds + 1)]})
     torch.cuda.synchronize()
+    hog = None
+    if starve:
+        # no room for a second record workspace (it is taken whole or not at all): the calls of the second stream share the first
+        # one's and wait for it -- the results are the same
+        e.dev_encode_body(pipes[0]["batches"][0]["d_src"].data_ptr(), pipes[0]["batches"][0]["data"].size, bsz, True, pipes[0]["bodies"][0].data_ptr(),
+                          pipes[0]["bodies"][0].numel(), pipes[0]["offs"][0].data_ptr(), pipes[0]["lens"][0].data_ptr(), pipes[0]["stream"].cuda_stream, level=1)
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        free, _ = torch.cuda.mem_get_info(dev)
+        hog = torch.empty(max(free - (48 << 20), 1 << 20), dtype=torch.uint8, device=dev)
     for r in range(rounds + 1):                       # every call of a round is enqueued before anything is waited for
         for pp in pipes:
             b = pp["batches"][r]; s = pp["stream"].cuda_stream
@@ -641,6 +650,7 @@ def test_gpu_duplex_body_calls_alternating_over_streams_of_one_ctx(orc, nstreams
                 prev = pp["batches"][r - 1]
                 assert int(pp["st"][r][:prev["nb"]].abs().sum().item()) == 0, (p, r)
                 assert np.array_equal(pp["outs"][r][:prev["data"].size].cpu().numpy(), prev["data"]), (p, r)
+    del hog
     e.close()
 
 
