@@ -568,8 +568,8 @@ def main():
         torch.cuda.synchronize()
 
         # Still untimed: do the pipelines pay on this process's streams?  Calls over several streams overlap only if the runtime
-        # has put the streams on different hardware queues and the launches stay staggered; about one process in seven was seen
-        # to run them at 495 ms per step instead of 304 (every step of the run, the serial steps after it at their usual speed).
+        # has put the streams on different hardware queues and the launches stay staggered; two processes of about forty were seen
+        # to run them at 495 ms per step instead of 305 (every step of the run, the serial steps after it at their usual speed).
         # So a few steps are clocked both ways before the timed region; a set of streams that does not pay is replaced once, and
         # if the new one does not pay either the timed steps run on one stream (config.pipelines says what ran).
         def clock(ps, n):
