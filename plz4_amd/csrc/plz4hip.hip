@@ -936,7 +936,7 @@ __global__ __launch_bounds__(64) void k_hc12_stitch(CodecArgs a)
 // Level 2 on independent blocks: the batch walk over the two tables (hc_mid_parse, lz4hc_lazy_device.inl), one wave per block,
 // the tables in the wave's slot of the HC workspace; records out, the emit kernels of level 1 behind it.
 // kD: blocks behind external segments (a.hcPfx; dictionary / linked blocks): the tables start from LZ4MID_fillHTable over the segment
-template <bool kD> __global__ __launch_bounds__(64) void k_hc_mid(CodecArgs a)
+template <bool kD> __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_hc_mid(CodecArgs a)
 {
     uint32_t* const tabs = (uint32_t*)(a.hcWork + (size_t)blockIdx.x * kHcWorkBytes);
     for (int i = next_block(a.queue); i < a.nBlocks; i = next_block(a.queue)) {
@@ -1433,6 +1433,10 @@ int ensure_hc(plz4hip_ctx* c)
     // overrides for experiments.
     int per = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, k_encode_rec_hc, 64, 0) != hipSuccess || per < 1) per = 8;
+    {   // (level 2's batch walk keeps its tables in these slots as well and holds more waves per CU than the one-thread parsers)
+        int perMid = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perMid, k_hc_mid<false>, 64, 0) == hipSuccess && perMid > per) per = perMid;
+    }
     if (const char* v = getenv("PLZ4HIP_HC_WAVES_PER_CU")) { const int w = atoi(v); if (w >= 1 && w <= per) per = w; }
     const int waves = c->cus * per;
     if (hipMalloc((void**)&c->d_hc, (size_t)waves * kHcWorkBytes) != hipSuccess) return fail(c, PLZ4HIP_E_NOMEM, "HC workspace");
