@@ -650,8 +650,9 @@ def test_gpu_duplex_body_calls_alternating_over_streams_of_one_ctx(orc, nstreams
                 prev = pp["batches"][r - 1]
                 assert int(pp["st"][r][:prev["nb"]].abs().sum().item()) == 0, (p, r)
                 assert np.array_equal(pp["outs"][r][:prev["data"].size].cpu().numpy(), prev["data"]), (p, r)
-    del hog
+    del hog, pipes, pp
     e.close()
+    torch.cuda.synchronize(); torch.cuda.empty_cache()      # (the memory goes back to the device, not into this process's cache: the next test starts other processes)
 
 
 @pytest.mark.gpu
@@ -687,7 +688,7 @@ def test_gpu_bench_modes_run_on_one_gpu():
     # when asked, one when asked; an odd number of steps leaves the pipelines with different numbers of calls
     for pipes, want in (((), 2), (("--pipelines", "3"), 3), (("--pipelines", "1"), 1)):
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--blocks", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                              *pipes], capture_output=True, text=True, timeout=600)
+                              *pipes], env=dict(os.environ, PLZ4_BENCH_NO_PIPE_CHECK="1"), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         line = json.loads(out.stdout.strip().splitlines()[-1])
         assert line["value"] > 0 and line["config"]["pipelines"] == want and line["serial_step"]["value"] > 0
@@ -699,4 +700,6 @@ def test_gpu_bench_modes_run_on_one_gpu():
                              env=dict(os.environ, PLZ4_BENCH_TEST_PIPE_CHECK=forced), capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         line = json.loads(out.stdout.strip().splitlines()[-1])
-        assert line["config"]["pipelines"] == want and line["config"]["pipeline_check"]["streams_replaced"] == int(forced)
+        # (64 blocks per step: whether two streams beat one here is noise, so a forced first failure may be followed by a real one)
+        rep = line["config"]["pipeline_check"]["streams_replaced"]
+        assert rep >= int(forced) and line["config"]["pipelines"] == (2 if rep < 2 else 1) and (forced != "2" or line["config"]["pipelines"] == want)
