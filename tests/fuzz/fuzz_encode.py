@@ -85,6 +85,49 @@ def main_gpu(iters, seed):
     return bad
 
 
+def main_gpu_body(iters, seed):
+    """The staged kernels on device-resident data, both builds of the parser: the fuzz inputs back to back, cut into blocks of three
+    sizes; plz4hip_dev_encode_body (k_l1_parse) and plz4hip_dev_duplex_body (k_l1_duplex, which also decodes the body the call before
+    it wrote) against the oracle's records."""
+    import torch
+    from plz4_amd._native import Engine
+    orc, eng = Oracle(), Engine(0)
+    rng = np.random.default_rng(seed)
+    data = np.concatenate([make(rng, it) for it in range(iters)])
+    dev = torch.device("cuda:0")
+    d_src = torch.from_numpy(data).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    bad = tot = 0
+    for bsz in (65536, 1 << 20, 4 << 20):
+        want = [orc.block_record(data[o:o + bsz], bsz, True) for o in range(0, data.size, bsz)]
+        body = np.concatenate(want); nb = len(want)
+        d_b = [torch.zeros(body.size + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
+        d_off = [torch.zeros(nb + 1, dtype=torch.int64, device=dev) for _ in range(2)]
+        d_len = torch.zeros(nb, dtype=torch.int32, device=dev)
+        d_out = torch.zeros(nb * bsz, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(nb, dtype=torch.int32, device=dev); d_st = torch.full((nb,), -9, dtype=torch.int32, device=dev)
+        eng.dev_encode_body(d_src.data_ptr(), data.size, bsz, True, d_b[0].data_ptr(), d_b[0].numel(), d_off[0].data_ptr(), d_len.data_ptr(), s, level=1)
+        eng.dev_duplex_body(d_src.data_ptr(), data.size, bsz, True, d_b[1].data_ptr(), d_b[1].numel(), d_off[1].data_ptr(), d_len.data_ptr(),
+                            d_b[0].data_ptr(), d_off[0].data_ptr(), nb, bsz, True, d_out.data_ptr(), bsz, bsz, d_res.data_ptr(), d_st.data_ptr(), s)
+        torch.cuda.synchronize()
+        for k in range(2):
+            tot += 1
+            got = d_b[k][:body.size].cpu().numpy()
+            if int(d_off[k][nb].item()) != body.size or not np.array_equal(got, body):
+                bad += 1
+                offs = d_off[k].cpu().numpy(); o = 0
+                for i, w in enumerate(want):
+                    if int(offs[i + 1] - offs[i]) != w.size or not np.array_equal(got[o:o + w.size], w):
+                        print("GPU BODY MISMATCH", "encode_body" if k == 0 else "duplex_body", "bsz", bsz, "block", i); break
+                    o += w.size
+        tot += 1
+        if int(d_st.abs().sum().item()) != 0 or not np.array_equal(d_out[:data.size].cpu().numpy(), data):
+            bad += 1; print("GPU BODY: the duplex call's decode side, bsz", bsz)
+    eng.close()
+    print("body: blocks of 64 KiB / 1 MiB / 4 MiB over", data.size, "bytes: checks", tot, "bad", bad)
+    return bad
+
+
 def main(iters=120, seed=3):
     emu, ref, orc = Emu(), Ref(), Oracle()
     rng = np.random.default_rng(seed)
@@ -107,5 +150,6 @@ def main(iters=120, seed=3):
 if __name__ == "__main__":
     args = [int(x) for x in sys.argv[1:] if x != "--gpu"]
     if "--gpu" in sys.argv:
-        sys.exit(1 if main_gpu(*(args + [120, 3][len(args):])) else 0)
+        a2 = args + [120, 3][len(args):]
+        sys.exit(1 if (main_gpu(*a2) + main_gpu_body(*a2)) else 0)
     sys.exit(1 if main(*args) else 0)
