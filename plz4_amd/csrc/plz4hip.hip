@@ -1111,7 +1111,11 @@ __device__ __forceinline__ void decode_rec_loop(const CodecArgs& a, uint8_t* dl)
         if ((threadIdx.x & 63u) == 0) { a.result[i] = r; a.status[i] = st; }
     }
 }
+#if defined(PLZ4_EXP_DEC_EU)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 6))) void k_decode_rec(CodecArgs a)
+#else
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_decode_rec(CodecArgs a)
+#endif
 {
     __shared__ __attribute__((aligned(16))) uint8_t dl[kDecLdsBytes];       // the vector path assembles each batch's output here
     decode_rec_loop<false>(a, dl);
@@ -1300,7 +1304,7 @@ struct plz4hip_ctx {
     // k_parse_gate) until that one has run its queue dry; it then moves into the CUs as the first one's workgroups leave, and the
     // emit kernels of the first call run beside it.
     int          l1Refused = 0;                // calls left before a refused second workspace is asked for again
-    uint32_t*    d_gate = nullptr; uint32_t gateSeq = 0; hipStream_t gateStream = nullptr; bool gatePending = false;
+    uint32_t*    d_gate = nullptr; uint32_t gateSeq = 0; hipStream_t gateStream = nullptr; bool gatePending = false; int gateBlocks = 0;
     // levels 3..11 on independent blocks: the list builder of the next group of blocks runs on this stream beside the walk of the
     // current one (launch_hc)
     hipStream_t  hcBuildStream = nullptr; hipEvent_t evHcFork = nullptr, evHcHist = nullptr, evHcChain[2] = {nullptr, nullptr}, evHcFree[2] = {nullptr, nullptr};
@@ -1372,6 +1376,22 @@ uint32_t* next_queue(plz4hip_ctx* c, hipStream_t s, hipError_t* e)
     c->qslot = (c->qslot + 1) % kQueueSlots;
     *e = hipMemsetAsync(q, 0, sizeof(uint32_t), s);
     return q;
+}
+
+// Zero a few bytes of device memory and wait for it -- on the ctx's own stream.  (A plain hipMemset would be the process's first
+// use of the NULL stream, which then takes one of the four hardware queues: the staging slots of the host-buffer calls end up
+// sharing queues and their chunks stop overlapping -- 2560 blocks through host memory 470 -> 790 ms, scripts/host_rate_ab.py.)
+inline hipError_t zero_sync(plz4hip_ctx* c, void* p, size_t n)
+{
+    hipError_t e = hipMemsetAsync(p, 0, n, c->stream);
+    return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
+}
+
+// ... and a small blocking copy the same way (hipMemcpy is a NULL-stream operation as well)
+inline hipError_t copy_sync(plz4hip_ctx* c, void* dst, const void* src, size_t n, hipMemcpyKind kind)
+{
+    hipError_t e = hipMemcpyAsync(dst, src, n, kind, c->stream);
+    return e == hipSuccess ? hipStreamSynchronize(c->stream) : e;
 }
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1533,7 +1553,7 @@ int plan_h12(plz4hip_ctx* c, int nBlocks, int maxLen, H12Plan* pl, bool lazy, bo
         c->d_h12 = nullptr; c->h12Bytes = 0;
         if (hipMalloc((void**)&c->d_h12, pl->total) == hipSuccess) {
             c->h12Bytes = pl->total;
-            HIPCHK(c, hipMemset(c->d_h12, 0, 256));
+            HIPCHK(c, zero_sync(c, c->d_h12, 256));
             break;
         }
         (void)hipGetLastError();
@@ -1822,7 +1842,7 @@ int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLe
                 c->d_h12 = nullptr; c->h12Bytes = 0;
                 const size_t need = slack + (size_t)perLists * listsPer;
                 if (hipMalloc((void**)&c->d_h12, need) != hipSuccess) { (void)hipGetLastError(); c->d_h12 = nullptr; lists = false; }
-                else { c->h12Bytes = need; HIPCHK(c, hipMemset(c->d_h12, 0, 256)); }
+                else { c->h12Bytes = need; HIPCHK(c, zero_sync(c, c->d_h12, 256)); }
             }
             const int perPre = lists ? perLists : perChain;
             if (getenv("PLZ4HIP_VERBOSE"))
@@ -1837,7 +1857,7 @@ int launch_hc_body(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLe
                     c->d_h12 = nullptr; c->h12Bytes = 0;
                     if (hipMalloc((void**)&c->d_h12, need) != hipSuccess) { c->d_h12 = nullptr; return fail(c, PLZ4HIP_E_NOMEM, "HC chain workspace"); }
                     c->h12Bytes = need;
-                    HIPCHK(c, hipMemset(c->d_h12, 0, 256));
+                    HIPCHK(c, zero_sync(c, c->d_h12, 256));
                 }
                 chainBytes = round_up((size_t)per * chainPer, 256);
                 rankBytes = round_up((size_t)per * (size_t)stride * 4, 256);
@@ -1968,14 +1988,18 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
         const int ng = nb - g0 < per ? nb - g0 : per;
         a.blk0 = g0; a.nBlocks = ng;
         a.queue = next_queue(c, s, &e); HIPCHK(c, e);
-        const bool signals = !mid;                                              // (the level-1 parse and the duplex launch)
+        const bool signals = !mid && !getenv("PLZ4HIP_EXP_NO_GATE");            // (the level-1 parse and the duplex launch)
         if (signals) {
-            if (c->gatePending && c->gateStream != s) hipLaunchKernelGGL(k_parse_gate, dim3(1), dim3(64), 0, s, (const uint32_t*)c->d_gate, c->gateSeq);
+            // (only behind a launch that fills the device: the parse launches of the host-buffer calls' chunks -- a third of the
+            // wave slots each -- are meant to share it, and behind the gate they would run one after the other: 2560 blocks through
+            // host memory 470 -> 680 ms)
+            if (c->gatePending && c->gateStream != s && c->gateBlocks >= 8 * c->cus)
+                hipLaunchKernelGGL(k_parse_gate, dim3(1), dim3(64), 0, s, (const uint32_t*)c->d_gate, c->gateSeq);
             if (c->gateSeq >= 0x7FFF0000u) {                                    // (once in two billion launches: start over)
-                HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipMemset(c->d_gate, 0, sizeof(uint32_t))); c->gateSeq = 0;
+                HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, zero_sync(c, c->d_gate, sizeof(uint32_t))); c->gateSeq = 0;
             }
             a.gate = c->d_gate; a.gateSeq = ++c->gateSeq;
-            c->gatePending = true; c->gateStream = s;
+            c->gatePending = true; c->gateStream = s; c->gateBlocks = ng;
         } else {
             a.gate = nullptr; c->gatePending = false;
         }
@@ -2153,7 +2177,10 @@ int plz4hip_ctx_create(int device, plz4hip_ctx** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_queues, kQueueSlots * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&c->d_gate, 256);
-    if (e == hipSuccess) e = hipMemset(c->d_gate, 0, 256);
+    // (on the ctx's own stream: a hipMemset would be this process's first use of the NULL stream, which then takes one of the
+    // four hardware queues -- the staging slots of the host-buffer calls end up sharing queues and their chunks stop overlapping:
+    // 2560 blocks 470 -> 790 ms, found with scripts/host_rate_ab.py)
+    if (e == hipSuccess) e = zero_sync(c, c->d_gate, 256);
     if (e == hipSuccess) e = hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device);
     int encPer = 0, decPer = 0;
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&encPer, k_encode_rec<kEncWavesPerWg>, 64 * kEncWavesPerWg, 0);
@@ -2696,7 +2723,7 @@ static int host_codec(plz4hip_ctx* c, int mode /*0 enc raw,1 dec raw,2 enc rec,3
         // the level-12 search kernel bounds its spins and raises this flag if it ever gives up (never seen): an engine failure,
         // not a result
         int32_t flag = 0;
-        HIPCHK(c, hipMemcpy(&flag, c->d_h12 + c->h12ErrOff, 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, copy_sync(c, &flag, c->d_h12 + c->h12ErrOff, 4, hipMemcpyDeviceToHost));
         if (flag) return fail(c, PLZ4HIP_E_DEVICE, "level-12 search kernel gave up (spin guard)");
     }
     return rc;
@@ -2828,7 +2855,7 @@ int plz4hip_xxh32_stream_sum(plz4hip_ctx* c, plz4hip_xxh32_stream* h, uint32_t* 
     ENTER_DEVICE(c);
     HIPCHK(c, hipEventSynchronize(h->done));
     XxhStream st;
-    HIPCHK(c, hipMemcpy(&st, h->d_state, sizeof st, hipMemcpyDeviceToHost));
+    HIPCHK(c, copy_sync(c, &st, h->d_state, sizeof st, hipMemcpyDeviceToHost));
     *out = xxh32_stream_sum(st);
     return PLZ4HIP_OK;
 }
@@ -2857,8 +2884,8 @@ int plz4hip_dict_create(plz4hip_ctx* c, const void* dict, int dictLen, plz4hip_d
     build_dict_table_slow(d->h_bytes.data(), dictLen, tab.data());
     hipError_t e = hipMalloc((void**)&d->d_bytes, 65536 + 64);
     if (e == hipSuccess) e = hipMalloc((void**)&d->d_table, 4096 * sizeof(uint32_t));
-    if (e == hipSuccess && dictLen) e = hipMemcpy(d->d_bytes, d->h_bytes.data(), (size_t)dictLen, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d->d_table, tab.data(), 4096 * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && dictLen) e = copy_sync(c, d->d_bytes, d->h_bytes.data(), (size_t)dictLen, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = copy_sync(c, d->d_table, tab.data(), 4096 * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&d->d_hc, 2 * (size_t)kHcWorkBytes);
     if (e == hipSuccess) {                                                       // clz4.NewDictCtxHC for both table strategies
         hipLaunchKernelGGL(k_hc_dict_prime, dim3(2), dim3(64), 0, c->stream, (const uint8_t*)d->d_bytes, dictLen, d->d_hc);
