@@ -263,9 +263,11 @@ int plz4hip_dev_duplex_body(plz4hip_ctx* ctx, const void* src, int64_t srcBytes,
  * per-ctx sanitised copy of srcLen: jobs enqueued on different streams of one ctx are ordered behind each other on the device
  * (an event wait, no host block); they never overlap.  The exception is the staged level-1 call on device-resident records
  * (plz4hip_dev_encode_records / _encode_body / _duplex_records / _duplex_body): a ctx keeps two record workspaces, so calls that
- * alternate over two streams overlap -- the parse launch of the later call waits on the device until the earlier one has handed
- * out its last block (the parse fills the chip by itself), then moves in as that one's workgroups leave, and the earlier call's
- * emit kernels run beside it (bench.py --pipelines: + 10 % over one stream). */
+ * alternate over two streams overlap -- behind a call that fills the chip (>= 8 blocks per CU) the parse launch of the later call
+ * waits on the device until the earlier one has handed out its last block, then moves in as that one's workgroups leave, and the
+ * earlier call's emit kernels run beside it (bench.py --pipelines: + 10 % over one stream).
+ * The library never issues work on the NULL stream (its own small copies and memsets run on a stream of the ctx): a process that
+ * does not use the NULL stream itself keeps all four hardware queues for the streams it passes in and the staging slots. */
 int plz4hip_dev_compress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
                          void* dst, int64_t dstStride, const int32_t* dstCap, int level, int maxLen, int32_t* result, void* stream);
 int plz4hip_dev_decompress(plz4hip_ctx* ctx, int nBlocks, const void* src, int64_t srcStride, const int32_t* srcLen,
