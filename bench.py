@@ -692,7 +692,7 @@ def main():
             eng.close()
             return
         out = {
-            "metric": "MiB/s enc+dec, 4MiB independent blocks, level %d, block-checksum on%s" % (args.level, " (duplex step)" if duplex else ""),
+            "metric": "MiB/s enc+dec, 4MiB independent blocks, level %d, block-checksum on%s" % (args.level, (" (duplex steps over %d streams)" % NPIPE if NPIPE > 1 else " (duplex step)") if duplex else ""),
             "value": round(world * mib / (ms_step * 1e-3), 1),
             "unit": "MiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
