@@ -1911,7 +1911,8 @@ int launch_l1(plz4hip_ctx* c, hipStream_t s, CodecArgs a, int nb, int maxLen, in
     const bool shared = (ws == nullptr);
     int wsi = 0;
     if (shared) {
-        // the workspace this stream used last; else one nobody has used yet; else the first one (and the wait below)
+        // the workspace this stream used last; else one whose last job is over (no second allocation for streams that merely take
+        // turns); else one that does not exist yet; else the first one (and the wait below)
         int nws = plz4hip_ctx::kL1Shared;
         if (const char* v = getenv("PLZ4HIP_L1_WORKSPACES")) { if (atoi(v) == 1) nws = 1; }
         int mine = -1, idle = -1, fresh = -1;
