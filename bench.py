@@ -253,8 +253,8 @@ def main():
     # the original stdout at the end.
     # The HIP runtime spreads a process's streams over four hardware queues unless told otherwise; this process has the NULL stream
     # (torch), the library's own, one per pipeline and -- with N > 1 -- the gather's and RCCL's.  Streams that share a queue
-    # run one behind the other (found the hard way twice: DESIGN 6.4); eight queues leave every stream its own.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # run one behind the other (found the hard way twice: DESIGN 6.4); sixteen queues leave every stream its own (eight still paired the two pipeline streams of an N > 1 rank).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
@@ -328,17 +328,23 @@ def main():
     B = args.blocks
     S = B * BSZ
     t0 = time.time()
-    NPIPE = args.pipelines if args.pipelines > 0 else (1 if multi else 2)
+    NPIPE = args.pipelines if args.pipelines > 0 else 2
     if not (bool(args.duplex) and args.level == 1 and not args.decode_only and args.pipe <= 1):
         NPIPE = 1
+    # N > 1: rank 0 has the assembled frame to hold and no room for a second full-size workspace, so there the two streams take one
+    # HALF of the step's blocks each (a step = one call per stream; buffers and workspaces are the one-stream step's, cut in two):
+    # 3072 + 3072 blocks over two streams run at 78 300 MiB/s on one GPU where 6144 on one stream run at 73 300.
+    SPLIT = multi and NPIPE > 1
+    if SPLIT:
+        NPIPE = 2
     if rank == 0:
         free0, total0 = torch.cuda.mem_get_info(dev)
         dup0 = bool(args.duplex) and args.level == 1 and not args.decode_only
-        plan = memory_plan(B, world, gather_rank0, dup0, 0.40, args.level, NPIPE)
+        plan = memory_plan(B, world, gather_rank0, dup0, 0.40, args.level, 1 if SPLIT else NPIPE)
         log("rank 0 memory plan, GiB (%d rank(s), gather %s): %s; device %.1f GiB, free %.1f GiB" %
             (world, args.gather if multi else "-", plan, total0 / 2**30, free0 / 2**30))
         if world == 1 and multi:                                               # the dry run also says what rank 0 of a full node would hold
-            log("rank 0 memory plan, GiB, for 8 ranks with the gather: %s" % memory_plan(B, 8, True, dup0, 0.40, args.level))
+            log("rank 0 memory plan, GiB, for 8 ranks with the gather: %s" % memory_plan(B, 8, True, dup0, 0.40, args.level, 1))
         # a fifth of the card stays free for the allocator and for whatever else lives there: a plan that does not leave it is
         # refused here rather than found out in the middle of a timed step (the level-1 workspace falling back to groups)
         # (the memory of a process that has just exited comes back asynchronously: a bench started right behind another GPU job
@@ -366,7 +372,7 @@ def main():
     # The batch is processed as `pipe` consecutive parts (like a writer emitting batch after batch): part p+1 is encoded
     # while part p is decoded on a second HIP stream -- the decoder needs no LDS and fills issue slots the LDS-bound
     # encoder leaves idle.  Every part has its own staging / sizes / offsets / body.
-    NP = max(1, min(args.pipe, B))
+    NP = 2 if (SPLIT and B >= 2) else max(1, min(args.pipe, B))
     bounds = [(B * i) // NP for i in range(NP + 1)]
     parts = []
     for i in range(NP):
@@ -384,18 +390,20 @@ def main():
             "res": torch.zeros(nb, dtype=torch.int32, device=dev),
             "st": torch.zeros(nb, dtype=torch.int32, device=dev),
         })
-    duplex = bool(args.duplex) and args.level == 1 and NP == 1 and not args.decode_only
+    SPLIT = SPLIT and NP == 2
+    duplex = bool(args.duplex) and args.level == 1 and (NP == 1 or SPLIT) and not args.decode_only
     if duplex:
         # two frame bodies: the decode side of a duplex call reads the one the previous step compacted while this step's goes to the other
-        pt = parts[0]
-        pt["bodies"] = [pt["body"], None]                                    # (the second one once the gate has told how large a body is)
-        pt["offs"] = [pt["off"], torch.zeros_like(pt["off"])]
-        pt["cur"] = 0
-        pt["gat_ev"] = [None, None]                                          # N > 1: the exchange that last read each body
-        pt["stream"] = None                                                  # (the current stream, below)
+        for pt in (parts if SPLIT else parts[:1]):
+            pt["bodies"] = [pt["body"], None]                                # (the second one once the gate has told how large a body is)
+            pt["offs"] = [pt["off"], torch.zeros_like(pt["off"])]
+            pt["cur"] = 0
+            pt["gat_ev"] = [None, None]                                      # N > 1: the exchange that last read each body
+            pt["stream"] = None                                              # (the current stream, below)
     else:
         NPIPE = 1
-    pipes = [parts[0]] if duplex else []                                     # the further pipelines once the gate has sized a body
+    # the pipelines: one stream -> the one part; N > 1 -> the two halves; one GPU -> further full-size ones once the gate has sized a body
+    pipes = (list(parts) if SPLIT else [parts[0]]) if duplex else []
     calls = {"n": 0}
     s_enc = torch.cuda.current_stream()
     s_dec = torch.cuda.Stream(device=dev) if NP > 1 else s_enc
@@ -411,12 +419,16 @@ def main():
                                 dst.data_ptr(), dst.numel(), torch.cuda.current_stream().cuda_stream)
         gather.setdefault("live", []).append((src_off, lens, dst_off))      # keep operands alive until the step ends
 
-    def frame_gather(pt):
+    def frame_gather(pt, which=None):
         """N > 1: rank 0 owns the io.Writer.  All-gather the record sizes (tiny), send every body to rank 0 over xGMI
-        (RCCL send/recv), interleave there: global block g = j*N + r is record j of rank r (plz4_amd/shard.py)."""
+        (RCCL send/recv), interleave there: global block g = j*N + r is record j of rank r (plz4_amd/shard.py).
+        which: the one of the part's two bodies to send (the duplex steps gather a step late); None: the current one."""
         from plz4_amd import shard
-        total_local = int(pt["off"][-1].item())
-        shard.gather_frame_body(pt["body"][:max(total_local, 1)], pt["len"], rank, world, scatter, gather, BSZ + 8)
+        body = pt["body"] if which is None else pt["bodies"][which]
+        off = pt["off"] if which is None else pt["offs"][which]
+        total_local = int(off[-1].item())
+        lens = (off[1:] - off[:-1]).to(torch.int32) if which is not None else pt["len"]   # (pt["len"] is the LAST call's)
+        shard.gather_frame_body(body[:max(total_local, 1)], lens, rank, world, scatter, gather, BSZ + 8)
 
     def step_decode(ev=None):
         """configs[2]: decode alone, over the frame bodies the parity gate's full step left in place"""
@@ -432,9 +444,36 @@ def main():
         """one duplex call: encode of this step's batch straight into a frame body + decode of the frame body the same pipeline's
         previous call wrote (one pipeline: the previous step's).  Calls alternate over the pipelines, each on its own stream."""
         gather["live"] = []
+        done = [duplex_call(ev[h] if ev else None) for h in range(len(pipes) if SPLIT else 1)]
+        # The exchanges of the step BEFORE run now, behind this step's calls: sizing an exchange reads the body's length on the
+        # host, which waits for that call's emit kernels -- with this step's calls already enqueued the GPU has work meanwhile, and
+        # the next parse starts beside the last emit.  (A body is not written again before the exchange that read it is over:
+        # gat_ev in duplex_call.)  flush_gathers() runs what is left: before the timed region starts and before it ends.
+        if gather_rank0:
+            flush_gathers(); pending_gathers.extend(done)
+        else:
+            pending_gathers.extend(done); flush_gathers()                   # (no exchange: only the step's events to record)
+
+    pending_gathers = []
+
+    def flush_gathers():
+        todo = list(pending_gathers); del pending_gathers[:]
+        for pt, cur, packed, e in todo:
+            if gather_rank0:
+                s_gat.wait_event(packed)
+                with torch.cuda.stream(s_gat):
+                    frame_gather(pt, cur)
+                    if e: e[3].record(s_gat)
+                    pt["gat_ev"][cur] = torch.cuda.Event(); pt["gat_ev"][cur].record(s_gat)
+            elif e:
+                e[3].record(pt["stream"] if pt["stream"] is not None else s_enc)
+            if e:
+                st_ = pt["stream"] if pt["stream"] is not None else s_enc
+                e[4].record(st_); e[5].record(st_)
+
+    def duplex_call(e):
         pt = pipes[calls["n"] % len(pipes)]; calls["n"] += 1
         st = pt["stream"] if pt["stream"] is not None else s_enc
-        e = ev[0] if ev else None
         prv = pt["cur"]; cur = 1 - prv
         if e: e[0].record(st)
         # (two bodies alternate: the one this call writes is the one the exchange of the step BEFORE LAST read -- that exchange has
@@ -449,15 +488,7 @@ def main():
         pt["cur"] = cur; pt["body"] = pt["bodies"][cur]; pt["off"] = pt["offs"][cur]
         packed = torch.cuda.Event(enable_timing=False) if e is None else e[2]
         packed.record(st)
-        if gather_rank0:
-            s_gat.wait_event(packed)
-            with torch.cuda.stream(s_gat):
-                frame_gather(pt)
-                if e: e[3].record(s_gat)
-                pt["gat_ev"][cur] = torch.cuda.Event(); pt["gat_ev"][cur].record(s_gat)
-        elif e:
-            e[3].record(st)
-        if e: e[4].record(st); e[5].record(st)
+        return pt, cur, packed, e
 
     def step(ev=None, serial=False):
         """ev: per part [enc0, enc1, cmp1, gat1, dec0, dec1] events."""
@@ -543,11 +574,12 @@ def main():
         d_out.zero_()                                                        # what the timed steps decode is checked again below
         # the same input every step, so the same body: the second one is that size + 2 % (compact skips what would not fit and
         # the check after the timed region would notice), which leaves rank 0 of an 8-GPU run room for the assembled frame
-        bcap = min(parts[0]["body"].numel(), int(C_bytes * 1.02) + (1 << 20))
-        parts[0]["bodies"][1] = torch.empty(bcap, dtype=torch.uint8, device=dev)
-        if NPIPE > 1:
-            parts[0]["stream"] = torch.cuda.Stream(device=dev)               # (a stream of its own like the others', not the default one)
-        for i in range(1, NPIPE):
+        for pt in pipes:
+            pt["bodies"][1] = torch.empty(pt["bodies"][0].numel(), dtype=torch.uint8, device=dev)
+            if NPIPE > 1:
+                pt["stream"] = torch.cuda.Stream(device=dev)                 # (a stream of its own like the others', not the default one)
+        bcap = parts[0]["bodies"][1].numel()
+        for i in range(1, NPIPE if not SPLIT else 1):
             # a further pipeline: its own stream, plaintext buffer, two bodies and offsets; primed with one encode of the batch, so
             # that its first duplex call has a body to decode (the library gives the second stream a record workspace of its own)
             q = {"b0": 0, "nb": B, "bytes": S, "src": d_src, "out": torch.zeros(S, dtype=torch.uint8, device=dev),
@@ -564,7 +596,7 @@ def main():
     for _ in range(args.warmup):
         step_decode() if args.decode_only else (step_duplex() if duplex else step())
     pipe_check = None
-    if duplex and len(pipes) > 1:
+    if duplex and len(pipes) > 1 and not SPLIT:
         # (untimed, whatever --warmup says: every further pipeline makes one call, which also puts its record workspace in place)
         torch.cuda.synchronize()
         while calls["n"] % len(pipes) != 0 or calls["n"] < len(pipes):
@@ -605,10 +637,14 @@ def main():
     if multi:
         dist.barrier()
     evs = [[[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in parts] for _ in range(args.steps)]
+    if duplex: flush_gathers()
     torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(evs[k])
+    if duplex: flush_gathers()                                               # (the last step's frame: K steps are K assembled frames)
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -620,13 +656,13 @@ def main():
         # every timed step decoded the body its pipeline's previous call wrote (the first ones the warm-up's or the gate's): the
         # plaintext must be back, and so must the plaintext of each pipeline's last body, decoded here outside the timed region
         for pt in pipes:
-            assert int(pt["st"].abs().sum().item()) == 0 and same_bytes(pt["out"], d_src), "duplex: round trip mismatch"
+            assert int(pt["st"].abs().sum().item()) == 0 and same_bytes(pt["out"], pt["src"]), "duplex: round trip mismatch"
             pt["out"].zero_()
             eng.dev_decode_records(pt["body"].data_ptr(), pt["off"].data_ptr(), pt["nb"], BSZ, True, pt["out"].data_ptr(), BSZ, BSZ,
                                    pt["res"].data_ptr(), pt["st"].data_ptr(), s_enc.cuda_stream)
             torch.cuda.synchronize()
-            assert int(pt["st"].abs().sum().item()) == 0 and same_bytes(pt["out"], d_src), "duplex: last body does not decode to the input"
-        if len(pipes) > 1:
+            assert int(pt["st"].abs().sum().item()) == 0 and same_bytes(pt["out"], pt["src"]), "duplex: last body does not decode to the input"
+        if len(pipes) > 1 and not SPLIT:
             # the further pipelines' buffers are not needed for the serial leg below (nor is the library's second workspace)
             del pipes[1:]
             pt = q = None
@@ -729,6 +765,8 @@ def main():
                 "step is one full encode and one full decode, the last body is decoded and checked after the timed region) -> frame body")
             out["config"]["duplex"] = True
             out["config"]["pipelines"] = NPIPE
+            if SPLIT:
+                out["config"]["calls_per_step"] = 2; out["config"]["blocks_per_call"] = [pt["nb"] for pt in parts]
             if pipe_check: out["config"]["pipeline_check"] = pipe_check
             if NPIPE > 1:
                 out["config"]["workload"] = out["config"]["workload"].replace(

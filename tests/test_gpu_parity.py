@@ -667,6 +667,8 @@ def test_gpu_bench_modes_run_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and "frame_gather" in line["ms"]
+    # (N > 1: a step is two calls, one half of the blocks on each of two streams; the exchanges run a step behind)
+    assert line["config"]["pipelines"] == 2 and line["config"]["calls_per_step"] == 2 and sum(line["config"]["blocks_per_call"]) == 64
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--blocks", "64", "--steps", "1", "--warmup", "1", "--decode-only"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
