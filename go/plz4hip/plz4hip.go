@@ -25,6 +25,15 @@ import (
 	"unsafe"
 )
 
+// The HIP runtime deals a process's streams onto four hardware queues unless GPU_MAX_HW_QUEUES says otherwise, and streams that share
+// a queue run behind each other (INTEGRATION.md section 3).  A ctx brings up to six streams of its own; the variable is read when
+// the runtime initialises, i.e. at the first engine call, so it is set here unless the operator has set it.
+func init() {
+	if os.Getenv("GPU_MAX_HW_QUEUES") == "" {
+		os.Setenv("GPU_MAX_HW_QUEUES", "16")
+	}
+}
+
 var (
 	ErrLz4Compress   = errors.New("lz4 fail compress; insufficient destination buffer") // == clz4.ErrLz4Compress
 	ErrLz4Decompress = errors.New("lz4 fail decompress")                                // == clz4.ErrLz4Decompress
